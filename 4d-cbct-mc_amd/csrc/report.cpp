@@ -1,0 +1,251 @@
+// report.cpp -- projection ASCII writer and voxel-file writer (wire formats of the reference).
+//
+//  * write_projection_ascii(): the per-projection output file of the reference engine
+//    (report_image, docker/mcgpu/MC-GPU_v1.3.cu:2783-2953): 20 comment lines,
+//    Nz blocks of Nx lines "%.8lf %.8lf %.8lf %.8lf", a blank line after each block, 6 footer comment
+//    lines.  This is what cbctmc/mc/projection.py:42 parses with np.loadtxt.  The reference prints
+//    with one fprintf per pixel on rank 0 (~0.9 s per 1848x768 projection); here rows are formatted
+//    by a pool of threads with an exact fixed-point formatter (falls back to snprintf when the
+//    8th decimal is within rounding doubt), so the bytes are identical to "%.8lf".
+//  * write_voxel_file(): the `.vox(.gz)` body written by cbctmc/mc/voxel_data.pyx:12-72 ("<mat> <dens:.6f>\n",
+//    blank line after each x-row, a second blank line after each z-slice) under the header fields of
+//    cbctmc/assets/templates/mcgpu_geometry.jinja2:66-73.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "host_model.hpp"
+
+namespace mcgpu {
+namespace {
+
+inline double rad2deg(double x) { return x * 180.0 / kPi; }
+
+// Append value formatted as "%.8lf".  Exact for the fast path: v in [0, 2^52/1e8).
+inline char* put_fixed8(char* out, double v) {
+  if (v >= 0.0 && v < 4.0e7) {
+    const double ip = floor(v);
+    const double f8 = (v - ip) * 1.0e8;  // (v-ip) exact; product within ~1.5e-8 of the true value
+    const double fl = floor(f8);
+    const double rem = f8 - fl;
+    if (fabs(rem - 0.5) > 1.0e-6) {
+      uint64_t frac = (uint64_t)fl + (rem > 0.5 ? 1u : 0u);
+      uint64_t iv = (uint64_t)ip;
+      if (frac >= 100000000ull) { frac -= 100000000ull; ++iv; }
+      char tmp[24];
+      int n = 0;
+      do { tmp[n++] = (char)('0' + iv % 10); iv /= 10; } while (iv);
+      while (n) *out++ = tmp[--n];
+      *out++ = '.';
+      for (int k = 7; k >= 0; --k) { out[k] = (char)('0' + frac % 10); frac /= 10; }
+      return out + 8;
+    }
+  }
+  return out + sprintf(out, "%.8lf", v);
+}
+
+}  // namespace
+
+std::string projection_file_name(const HostModel& m, int p) {
+  const SimConfig& c = m.cfg;
+  float seq;
+  if (c.enable_specific_angles == 0) seq = (float)rad2deg(c.initial_angle + p * c.D_angle);
+  else seq = c.specific_angles[p];
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s_%010.6fdeg", c.file_output.c_str(), seq);
+  return buf;
+}
+
+size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, unsigned long long total_histories,
+                              double seconds, const std::string& file_name, int n_threads) {
+  const SimConfig& c = m.cfg;
+  const DetectorPose& d0 = m.detector[0];
+  const int nx = d0.nx, nz = d0.nz;
+  const size_t npix = (size_t)nx * nz;
+  float cur, seq;
+  if (c.enable_specific_angles == 0) {
+    cur = (float)rad2deg(c.initial_angle + p * c.D_angle);
+    seq = cur;
+    if (cur >= (360 - 0.0001)) cur -= 360;
+  } else {
+    cur = c.specific_angles[p];
+    seq = cur;
+  }
+  FILE* fp = fopen(file_name.c_str(), "wb");
+  if (!fp) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " can not be opened!!");
+  static char iobuf[1 << 22];
+  setvbuf(fp, iobuf, _IOFBF, sizeof iobuf);
+  size_t bytes = 0;
+  const SourcePose& s = m.source[p];
+  bytes += fprintf(fp, "# \n");
+  bytes += fprintf(fp, "#     *****************************************************************************\n");
+  bytes += fprintf(fp, "#     ***   MC CBCT projection engine for AMD MI355X (MC-GPU v1.3 file contract)  ***\n");
+  bytes += fprintf(fp, "#     ***                                                                       ***\n");
+  bytes += fprintf(fp, "#     ***   drop-in for cbctmc.mc: same inputs, same per-projection output files  ***\n");
+  bytes += fprintf(fp, "#     *****************************************************************************\n");
+  bytes += fprintf(fp, "# \n");
+  bytes += fprintf(fp, "#  *** SIMULATION IN THE GPU USING HIP ***\n");
+  bytes += fprintf(fp, "#\n");
+  bytes += fprintf(fp, "#  Image created counting the energy arriving at each pixel: ideal energy integrating detector.\n");
+  bytes += fprintf(fp, "#  Pixel value units: eV/cm^2 per history (energy fluence).\n");
+  bytes += fprintf(fp, "#  CT projection %d of %d: angle from X axis = %lf (mod 360deg), %lf (no mod 360deg) \n", p + 1, c.num_projections,
+                   (double)cur, (double)seq);
+  bytes += fprintf(fp, "#  Focal spot position = (%.8f,%.8f,%.8f), cone beam direction = (%.8f,%.8f,%.8f)\n", s.pos[0], s.pos[1], s.pos[2],
+                   s.dir[0], s.dir[1], s.dir[2]);
+  bytes += fprintf(fp, c.enable_specific_angles == 0 ? "#  Specific angles enabled: NO\n" : "#  Specific angles enabled: YES\n");
+  bytes += fprintf(fp, "#  Pixel size:  %lf x %lf = %lf cm^2\n", 1.0 / (double)d0.inv_pixel_size_X, 1.0 / (double)d0.inv_pixel_size_Z,
+                   1.0 / (double)(d0.inv_pixel_size_X * d0.inv_pixel_size_Z));
+  bytes += fprintf(fp, "#  Number of pixels in X and Z:  %d  %d\n", nx, nz);
+  bytes += fprintf(fp, "#  (X rows given first, a blank line separates the different Z values)\n");
+  bytes += fprintf(fp, "# \n");
+  bytes += fprintf(fp, "#  [NON-SCATTERED] [COMPTON] [RAYLEIGH] [MULTIPLE-SCATTING]\n");
+  bytes += fprintf(fp, "# ==========================================================\n");
+
+  const double SCALE = 1.0 / 100.0f;  // 1/SCALE_eV (MC-GPU_v1.3.cu:2860)
+  const double NORM = SCALE * d0.inv_pixel_size_X * d0.inv_pixel_size_Z / ((double)total_histories);
+
+  int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  T = std::min(T, nz);
+  if (npix < 65536) T = 1;
+  std::vector<std::string> chunks(T);
+  std::vector<double> integral(T, 0.0), maxval(T, -100.0);
+  std::vector<long> maxpix(T, 0);
+  auto work = [&](int t) {
+    const int z0 = (int)((long)nz * t / T), z1 = (int)((long)nz * (t + 1) / T);
+    std::string& out = chunks[t];
+    out.resize((size_t)(z1 - z0) * ((size_t)nx * 4 * 28 + 1) + 64);
+    char* w = &out[0];
+    double integ = 0.0, mx = -100.0;
+    long mp = 0;
+    for (int j = z0; j < z1; ++j) {
+      size_t pix = (size_t)j * nx;
+      for (int i = 0; i < nx; ++i, ++pix) {
+        const double e0 = (double)image[pix], e1 = (double)image[pix + npix], e2 = (double)image[pix + 2 * npix],
+                     e3 = (double)image[pix + 3 * npix];
+        w = put_fixed8(w, NORM * e0); *w++ = ' ';
+        w = put_fixed8(w, NORM * e1); *w++ = ' ';
+        w = put_fixed8(w, NORM * e2); *w++ = ' ';
+        w = put_fixed8(w, NORM * e3); *w++ = '\n';
+        const double tot = e0 + e1 + e2 + e3;
+        if (tot > mx) { mx = tot; mp = (long)pix; }
+        integ += tot;
+      }
+      *w++ = '\n';
+    }
+    out.resize((size_t)(w - &out[0]));
+    integral[t] = integ;
+    maxval[t] = mx;
+    maxpix[t] = mp;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  double energy_integral = 0.0, maximum = -100.0;
+  long max_pixel = 0;
+  for (int t = 0; t < T; ++t) {
+    bytes += fwrite(chunks[t].data(), 1, chunks[t].size(), fp);
+    energy_integral += integral[t];  // NB: summed per band; the footer's %.3lf is insensitive to the order
+    if (maxval[t] > maximum) { maximum = maxval[t]; max_pixel = maxpix[t]; }
+  }
+  bytes += fprintf(fp, "#   *** Simulation REPORT: ***\n");
+  bytes += fprintf(fp, "#       Fraction of energy detected (over the mean energy of the spectrum): %.3lf%%\n",
+                   100.0 * SCALE * (energy_integral / (double)total_histories) / (double)m.spectrum.mean_energy);
+  bytes += fprintf(fp, "#       Maximum energy detected in pixel %i: (x,y)=(%i,%i) -> pixel value = %lf eV/cm^2\n", (int)max_pixel,
+                   (int)(max_pixel % nx), (int)(max_pixel / nx), NORM * maximum);
+  bytes += fprintf(fp, "#       Simulated x rays:    %lld\n", (long long)total_histories);
+  bytes += fprintf(fp, "#       Simulation time [s]: %.2f\n", seconds);
+  if (seconds > 0.000001) bytes += fprintf(fp, "#       Speed [x-rays/sec]:  %.2f\n\n", ((double)total_histories) / seconds);
+  if (fclose(fp) != 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!");
+  return bytes;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t write_voxel_file(const std::string& path, const int n[3], const float spacing_cm[3], const uint8_t* material,
+                        const float* density, bool gzip) {
+  const size_t nx = n[0], ny = n[1], nz = n[2];
+  std::string head;
+  char buf[512];
+  head += "# MC-GPU voxelized geometry (penEasy 2008 voxel format); x runs first, then y, then z\n";
+  head += "[SECTION VOXELS HEADER v.2008-04-13]\n";
+  snprintf(buf, sizeof buf, "%d %d %d  # SIZE IN X, Y, Z\n", n[0], n[1], n[2]);
+  head += buf;
+  snprintf(buf, sizeof buf, "%.9g %.9g %.9g  # VOXEL SPACING IN X, Y, Z\n", spacing_cm[0], spacing_cm[1], spacing_cm[2]);
+  head += buf;
+  head += "1  # COLUMN NUMBER WHERE MATERIAL ID IS LOCATED\n2  # COLUMN NUMBER WHERE MASS DENSITY IS LOCATED\n"
+          "1  # BLANK LINES AT END OF X,Y-CYCLES (1=YES, 0=NO)\n[END OF VXH SECTION]\n#\n# >>>> DATA BEGINS >>>>\n";
+  gzFile gz = nullptr;
+  FILE* fp = nullptr;
+  if (gzip) {
+    gz = gzopen(path.c_str(), "wb1");
+    if (!gz) throw Error(-3, "!!ERROR!! Voxel file " + path + " can not be opened for writing!!");
+    gzbuffer(gz, 1 << 20);
+  } else {
+    fp = fopen(path.c_str(), "wb");
+    if (!fp) throw Error(-3, "!!ERROR!! Voxel file " + path + " can not be opened for writing!!");
+  }
+  size_t bytes = 0;
+  auto emit = [&](const char* p, size_t len) {
+    if (gz) gzwrite(gz, p, (unsigned)len); else fwrite(p, 1, len, fp);
+    bytes += len;
+  };
+  emit(head.data(), head.size());
+  // format one z-slice at a time, rows in parallel
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::string> rows(T);
+  for (size_t k = 0; k < nz; ++k) {
+    auto work = [&](int t) {
+      const size_t j0 = ny * t / T, j1 = ny * (t + 1) / T;
+      std::string& out = rows[t];
+      out.resize((j1 - j0) * (nx * 24 + 1) + 8);
+      char* w = &out[0];
+      for (size_t j = j0; j < j1; ++j) {
+        const size_t base = (k * ny + j) * nx;
+        for (size_t i = 0; i < nx; ++i) {
+          unsigned mv = material[base + i];
+          if (mv >= 100) { *w++ = (char)('0' + mv / 100); mv %= 100; *w++ = (char)('0' + mv / 10); *w++ = (char)('0' + mv % 10); }
+          else if (mv >= 10) { *w++ = (char)('0' + mv / 10); *w++ = (char)('0' + mv % 10); }
+          else *w++ = (char)('0' + mv);
+          *w++ = ' ';
+          // "%.6f" of the float density (python f'{x:.6f}' formats the float promoted to double)
+          const double dv = (double)density[base + i];
+          const double ip = floor(dv);
+          const double f6 = (dv - ip) * 1.0e6;
+          const double fl = floor(f6), rem = f6 - fl;
+          if (dv >= 0.0 && dv < 1.0e9 && fabs(rem - 0.5) > 1.0e-6) {
+            uint64_t frac = (uint64_t)fl + (rem > 0.5 ? 1u : 0u), iv = (uint64_t)ip;
+            if (frac >= 1000000ull) { frac -= 1000000ull; ++iv; }
+            char tmp[24];
+            int nn = 0;
+            do { tmp[nn++] = (char)('0' + iv % 10); iv /= 10; } while (iv);
+            while (nn) *w++ = tmp[--nn];
+            *w++ = '.';
+            for (int q = 5; q >= 0; --q) { w[q] = (char)('0' + frac % 10); frac /= 10; }
+            w += 6;
+          } else {
+            w += sprintf(w, "%.6f", dv);
+          }
+          *w++ = '\n';
+        }
+        *w++ = '\n';
+      }
+      out.resize((size_t)(w - &out[0]));
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; ++t) emit(rows[t].data(), rows[t].size());
+    emit("\n", 1);
+  }
+  if (gz) gzclose(gz); else fclose(fp);
+  return bytes;
+}
+
+}  // namespace mcgpu

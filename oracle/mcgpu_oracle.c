@@ -1,0 +1,612 @@
+/*
+ * oracle/mcgpu_oracle.c -- TEST INFRASTRUCTURE ONLY (see mcgpu_oracle.h).
+ *
+ * CPU restatement of the reference photon-history loop.  Every function cites the lines of
+ * docker/mcgpu/MC-GPU_kernel_v1.3.cu ("K.cu") it follows; the branches taken are those of the
+ * reference's CPU build (USING_CUDA undefined).  Operand types (float vs double) and operation
+ * order are kept as the C expressions of the reference evaluate them, so that with
+ * ORACLE_MATH_LIBM the tallies are bit-identical to oracle/_ref.  Compile with
+ * -ffp-contract=off and without fast-math (oracle/Makefile).
+ *
+ * ORACLE_MATH_PORTABLE swaps the libm calls inside the history loop (logf, expf, powf, sin,
+ * cos) for the deterministic "pm_" functions below, which use only IEEE +,-,*,/ on doubles
+ * and bit manipulation; the HIP compat kernel restates the same functions, which makes
+ * GPU-vs-oracle comparisons bit-exact.
+ */
+#include "mcgpu_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXMAT 25
+#define MAXSHELLS 40
+#define NPRAY 128
+#define EPS_SRC 0.000015f
+#define NEG_INF_DIST (-500000.0f)
+
+typedef struct { float x, y, z; } f3;
+typedef struct { int x, y; } i2;
+
+/* reference wire layouts (MC-GPU_v1.3.h:155-169 and :190-208) */
+typedef struct {
+  f3 position, direction;
+  float rot_fan[9], cos_theta_low, phi_low, D_cos_theta, D_phi, max_height_at_y1cm;
+} src_t;
+typedef struct {
+  float sdd, lateral_displacement;
+  f3 corner_min_rotated_to_Y, center;
+  float rot_inv[9], width_X, height_Z, inv_pixel_size_X, inv_pixel_size_Z;
+  int num_pixels_x, num_pixels_y, total_num_pixels, rotation_flag;
+} det_t;
+
+/* ------------------------------------------------------------------------------------------
+ * Portable math.  Algorithms: log via 2*atanh((m-1)/(m+1)) series on m in [sqrt(1/2),sqrt(2));
+ * exp via Cody-Waite reduction by ln2 and a degree-13 Taylor polynomial; sin/cos via reduction
+ * by pi/2 (two-part constant) and Taylor polynomials on |r| <= pi/4.  No fma, no libm.
+ * ------------------------------------------------------------------------------------------ */
+static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+static inline double pm_log(double x)
+{
+  uint64_t b = d2u(x);
+  int e = (int)((b >> 52) & 0x7ff) - 1023;
+  double m = u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+  if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double p = 0.047619047619047616;            /* 1/21 */
+  p = p * z + 0.052631578947368418;           /* 1/19 */
+  p = p * z + 0.058823529411764705;           /* 1/17 */
+  p = p * z + 0.066666666666666666;           /* 1/15 */
+  p = p * z + 0.076923076923076927;           /* 1/13 */
+  p = p * z + 0.090909090909090912;           /* 1/11 */
+  p = p * z + 0.11111111111111110;            /* 1/9  */
+  p = p * z + 0.14285714285714285;            /* 1/7  */
+  p = p * z + 0.20000000000000001;            /* 1/5  */
+  p = p * z + 0.33333333333333331;            /* 1/3  */
+  double r = 2.0 * s + (2.0 * s) * (z * p);
+  return (double)e * 0.69314718055994529 + r;
+}
+
+static inline double pm_exp(double x)
+{
+  if (x < -745.0) return 0.0;
+  if (x > 709.0) return INFINITY;
+  double kf = floor(x * 1.4426950408889634 + 0.5);
+  double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+  double p = 1.6059043836821613e-10;          /* 1/13! */
+  p = p * r + 2.08767569878681e-09;           /* 1/12! */
+  p = p * r + 2.505210838544172e-08;          /* 1/11! */
+  p = p * r + 2.755731922398589e-07;          /* 1/10! */
+  p = p * r + 2.7557319223985893e-06;         /* 1/9!  */
+  p = p * r + 2.48015873015873e-05;           /* 1/8!  */
+  p = p * r + 0.0001984126984126984;          /* 1/7!  */
+  p = p * r + 0.001388888888888889;           /* 1/6!  */
+  p = p * r + 0.008333333333333333;           /* 1/5!  */
+  p = p * r + 0.041666666666666664;           /* 1/4!  */
+  p = p * r + 0.16666666666666666;            /* 1/3!  */
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  int k = (int)kf;
+  /* scale by 2^k in two exact steps so that results in the double-denormal range stay defined */
+  int k1 = k / 2, k2 = k - k1;
+  double s1 = u2d((uint64_t)(k1 + 1023) << 52), s2 = u2d((uint64_t)(k2 + 1023) << 52);
+  return (p * s1) * s2;
+}
+
+static inline void pm_sincos(double x, double *sn, double *cs)
+{
+  double kf = floor(x * 0.63661977236758138 + 0.5);
+  int q = ((int)kf) & 3;
+  double r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11;
+  double z = r * r;
+  double ps = -8.2206352466243295e-18;        /* -1/19! */
+  ps = ps * z + 2.8114572543455206e-15;       /*  1/17! */
+  ps = ps * z - 7.6471637318198164e-13;       /* -1/15! */
+  ps = ps * z + 1.6059043836821613e-10;       /*  1/13! */
+  ps = ps * z - 2.505210838544172e-08;        /* -1/11! */
+  ps = ps * z + 2.7557319223985893e-06;       /*  1/9!  */
+  ps = ps * z - 0.0001984126984126984;        /* -1/7!  */
+  ps = ps * z + 0.008333333333333333;         /*  1/5!  */
+  ps = ps * z - 0.16666666666666666;          /* -1/3!  */
+  double s = r + r * (z * ps);
+  double pc = 4.1103176233121648e-19;         /*  1/20! */
+  pc = pc * z - 1.5619206968586225e-16;       /* -1/18! */
+  pc = pc * z + 4.7794773323873853e-14;       /*  1/16! */
+  pc = pc * z - 1.1470745597729725e-11;       /* -1/14! */
+  pc = pc * z + 2.08767569878681e-09;         /*  1/12! */
+  pc = pc * z - 2.755731922398589e-07;        /* -1/10! */
+  pc = pc * z + 2.48015873015873e-05;         /*  1/8!  */
+  pc = pc * z - 0.001388888888888889;         /* -1/6!  */
+  pc = pc * z + 0.041666666666666664;         /*  1/4!  */
+  pc = pc * z - 0.5;
+  double c = 1.0 + z * pc;
+  if (q == 0) { *sn = s; *cs = c; }
+  else if (q == 1) { *sn = c; *cs = -s; }
+  else if (q == 2) { *sn = -s; *cs = -c; }
+  else { *sn = -c; *cs = s; }
+}
+
+double oracle_pm_log(double x) { return pm_log(x); }
+double oracle_pm_exp(double x) { return pm_exp(x); }
+void oracle_pm_sincos(double x, double *s, double *c) { pm_sincos(x, s, c); }
+
+/* math dispatch ---------------------------------------------------------------------------- */
+static inline float m_logf(float x, int pm) { return pm ? (float)pm_log((double)x) : logf(x); }
+static inline float m_expf(float x, int pm) { return pm ? (float)pm_exp((double)x) : expf(x); }
+static inline float m_powf(float b, float y, int pm) { return pm ? (float)pm_exp((double)y * pm_log((double)b)) : powf(b, y); }
+static inline void m_sincos(double x, double *s, double *c, int pm)
+{ if (pm) pm_sincos(x, s, c); else { *s = sin(x); *c = cos(x); } }
+
+/* ------------------------------------------------------------------------------------------
+ * RANECU  (K.cu:965-1015 ranecu/ranecu_double, :919-950 abMODm, :841-894 init_PRNG)
+ * ------------------------------------------------------------------------------------------ */
+static inline int ranecu_step(i2 *s)
+{
+  int i1 = s->x / 53668;
+  s->x = 40014 * (s->x - i1 * 53668) - i1 * 12211;
+  int k = s->y / 52774;
+  s->y = 40692 * (s->y - k * 52774) - k * 3791;
+  if (s->x < 0) s->x += 2147483563;
+  if (s->y < 0) s->y += 2147483399;
+  k = s->x - s->y;
+  if (k < 1) k += 2147483562;
+  return k;
+}
+static inline float ranecu(i2 *s, uint64_t *cnt) { ++*cnt; return (float)ranecu_step(s) * 4.65661305739e-10f; }
+static inline double ranecu_d(i2 *s, uint64_t *cnt) { ++*cnt; return (double)ranecu_step(s) * 4.6566130573917692e-10; }
+
+static int abmodm(int m, int a, int s)
+{
+  int q, k, p = -m;
+  while (a > 32768) {
+    if (a & 1) { p += s; if (p > 0) p -= m; }
+    a >>= 1;
+    s = (s - m) + s;
+    if (s < 0) s += m;
+  }
+  q = m / a;
+  k = s / q;
+  s = a * (s - k * q) - k * (m - q * a);
+  while (s < 0) s += m;
+  p += s;
+  if (p < 0) p += m;
+  return p;
+}
+static int pow_mod(int m, int a, unsigned long long leap)
+{
+  int y = 1, z = a;
+  for (;;) {
+    if (leap & 1ULL) { leap >>= 1; y = abmodm(m, z, y); if (leap == 0) break; }
+    else leap >>= 1;
+    z = abmodm(m, z, z);
+  }
+  return y;
+}
+static void init_prng(int batch, int hpt, int seed_input, i2 *seed)
+{
+  unsigned long long leap = ((unsigned long long)(batch + 1)) * (unsigned long long)(hpt * 256);
+  seed->x = abmodm(2147483563, seed_input, pow_mod(2147483563, 40014, leap));
+  seed->y = abmodm(2147483399, seed_input, pow_mod(2147483399, 40692, leap));
+}
+void oracle_init_prng(int batch, int hpt, int seed_input, int *seed2)
+{ i2 s; init_prng(batch, hpt, seed_input, &s); seed2[0] = s.x; seed2[1] = s.y; }
+float oracle_ranecu(int *seed2)
+{ i2 s = { seed2[0], seed2[1] }; uint64_t c = 0; float r = ranecu(&s, &c); seed2[0] = s.x; seed2[1] = s.y; return r; }
+double oracle_ranecu_double(int *seed2)
+{ i2 s = { seed2[0], seed2[1] }; uint64_t c = 0; double r = ranecu_d(&s, &c); seed2[0] = s.x; seed2[1] = s.y; return r; }
+int oracle_abmodm(int m, int a, int s) { return abmodm(m, a, s); }
+/* update_seed_PRNG, MC-GPU_v1.3.cu:3456-3485 */
+int oracle_update_seed(int batch_number, unsigned long long total_histories, int seed)
+{
+  if (batch_number == 0) return seed;
+  return abmodm(2147483563, seed, pow_mod(2147483563, 40014, total_histories * (unsigned long long)(batch_number * 256)));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry helpers: move_to_bbox (K.cu:714-805), locate_voxel (K.cu:1033-1065)
+ * ------------------------------------------------------------------------------------------ */
+static inline float entry_dist(float p, float d, float size)
+{
+  if (d > EPS_SRC) return (p > 0.0f) ? 0.0f : EPS_SRC + (-p) / d;
+  if (d < -EPS_SRC) return (p < size) ? 0.0f : EPS_SRC + (size - p) / d;
+  return NEG_INF_DIST;
+}
+static void move_to_bbox(f3 *pos, const f3 *dir, const float *bbox, int *flag)
+{
+  float dy = entry_dist(pos->y, dir->y, bbox[1]);
+  float dx = entry_dist(pos->x, dir->x, bbox[0]);
+  float dz = entry_dist(pos->z, dir->z, bbox[2]);
+  if ((dy > dx) && (dy > dz)) dz = dy;
+  else if (dx > dz) dz = dx;
+  pos->x += dz * dir->x; pos->y += dz * dir->y; pos->z += dz * dir->z;
+  if ((pos->x < 0.0f) || (pos->x > bbox[0]) || (pos->y < 0.0f) || (pos->y > bbox[1]) || (pos->z < 0.0f) || (pos->z > bbox[2])) {
+    pos->x -= dz * dir->x; pos->y -= dz * dir->y; pos->z -= dz * dir->z;
+    *flag = -111;
+  }
+}
+static inline int locate_voxel(const oracle_tables *T, const f3 *p)
+{
+  if ((p->y < EPS_SRC) || (p->y > (T->size_bbox[1] - EPS_SRC)) || (p->x < EPS_SRC) || (p->x > (T->size_bbox[0] - EPS_SRC)) ||
+      (p->z < EPS_SRC) || (p->z > (T->size_bbox[2] - EPS_SRC)))
+    return -1;
+  int ix = (int)(p->x * T->inv_voxel_size[0]);
+  int iy = (int)(p->y * T->inv_voxel_size[1]);
+  int iz = (int)(p->z * T->inv_voxel_size[2]);
+  return ix + iy * T->num_voxels[0] + iz * T->num_voxels[0] * T->num_voxels[1];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * source (K.cu:626-686): Walker-alias energy + rejection-sampled direction in the fan, rotate, enter bbox
+ * ------------------------------------------------------------------------------------------ */
+static void source(const oracle_tables *T, const src_t *S, const det_t *D, f3 *pos, f3 *dir, float *energy, i2 *seed, int *absvox,
+                   int pm, uint64_t *cnt)
+{
+  float RN = ranecu(seed, cnt) * T->num_bins_espc;
+  int ip = (int)RN;
+  float fr = RN - (float)ip;
+  int bin = (fr < T->espc_cutoff[ip]) ? ip : (int)T->espc_alias[ip];
+  *energy = T->espc[bin] + ranecu(seed, cnt) * (T->espc[bin + 1] - T->espc[bin]);
+  do {
+    dir->z = S->cos_theta_low + ranecu(seed, cnt) * S->D_cos_theta;
+    float phi = S->phi_low + ranecu(seed, cnt) * S->D_phi;
+    float sth = sqrtf(1.0f - dir->z * dir->z);
+    double sd, cd;
+    m_sincos((double)phi, &sd, &cd, pm);
+    float sphi = (float)sd, cphi = (float)cd;
+    dir->y = sth * sphi;
+    dir->x = sth * cphi;
+  } while (fabsf(dir->z / (dir->y + 1.0e-7f)) > S->max_height_at_y1cm);
+  if (D->rotation_flag == 1) {
+    float tx = dir->x, ty = dir->y;
+    dir->x = S->rot_fan[0] * tx + S->rot_fan[1] * ty + S->rot_fan[2] * dir->z;
+    dir->y = S->rot_fan[3] * tx + S->rot_fan[4] * ty + S->rot_fan[5] * dir->z;
+    dir->z = S->rot_fan[6] * tx + S->rot_fan[7] * ty + S->rot_fan[8] * dir->z;
+  }
+  *pos = S->position;
+  move_to_bbox(pos, dir, T->size_bbox, absvox);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * rotate_double (K.cu:1103-1148, PENELOPE DIRECT)
+ * ------------------------------------------------------------------------------------------ */
+static void rotate_dir(f3 *d, double costh, double phi, int pm)
+{
+  double DXY, NORM, cosphi, sinphi, SDT;
+  DXY = d->x * d->x + d->y * d->y;             /* float arithmetic, then widened (as in the reference) */
+  m_sincos(phi, &sinphi, &cosphi, pm);
+  NORM = DXY + d->z * d->z;
+  if (fabs(NORM - 1.0) > 1.0e-14) {
+    NORM = 1.0 / sqrt(NORM);
+    d->x = NORM * d->x; d->y = NORM * d->y; d->z = NORM * d->z;
+    DXY = d->x * d->x + d->y * d->y;
+  }
+  if (DXY > 1.0e-28) {
+    SDT = sqrt((1.0 - costh * costh) / DXY);
+    float xin = d->x;
+    d->x = d->x * costh + SDT * (xin * d->z * cosphi - d->y * sinphi);
+    d->y = d->y * costh + SDT * (d->y * d->z * cosphi + xin * sinphi);
+    d->z = d->z * costh - DXY * SDT * cosphi;
+  } else {
+    SDT = sqrt(1.0 - costh * costh);
+    d->y = SDT * sinphi;
+    if (d->z > 0.0) { d->x = SDT * cosphi; d->z = costh; }
+    else { d->x = -SDT * cosphi; d->z = -costh; }
+  }
+}
+void oracle_rotate(float *dir3, double costh, double phi, int math_mode)
+{ f3 d = { dir3[0], dir3[1], dir3[2] }; rotate_dir(&d, costh, phi, math_mode); dir3[0] = d.x; dir3[1] = d.y; dir3[2] = d.z; }
+
+/* ------------------------------------------------------------------------------------------
+ * GRAa (K.cu:1181-1246): Rayleigh angle by RITA sampling of the squared form factor
+ * ------------------------------------------------------------------------------------------ */
+static void graa(const oracle_tables *T, float energy, double *costh, int mat, float pmax_current, i2 *seed, uint64_t *cnt)
+{
+  double xmax = ((double)energy) * 8.065535669099010e-5;
+  double xl = (double)T->xco[(mat + 1) * NPRAY - 1];
+  double x2max = (xmax * xmax < xl) ? xmax * xmax : xl;
+  if (xmax < 0.01) {
+    do { *costh = 1.0 - ranecu_d(seed, cnt) * 2.0; } while (ranecu_d(seed, cnt) > (((*costh) * (*costh) + 1.0) * 0.5));
+    return;
+  }
+  for (;;) {
+    double ru = ranecu_d(seed, cnt) * (double)pmax_current;
+    int itn = (int)(ru * (NPRAY - 1));
+    int i = (int)T->itlco[itn + mat * NPRAY];
+    int j = (int)T->ituco[itn + mat * NPRAY];
+    if ((j - i) > 1) {
+      do {
+        int k = (i + j) >> 1;
+        if (ru > T->pco[k - 1 + mat * NPRAY]) i = k; else j = k;
+      } while ((j - i) > 1);
+    }
+    int q = i - 1 + mat * NPRAY;
+    double rr = ru - T->pco[q];
+    double xx;
+    if (rr > 1e-16) {
+      double d = (double)(T->pco[q + 1] - T->pco[q]);
+      float a = T->aco[q], b = T->bco[q], x0 = T->xco[q];
+      xx = (double)x0 + (double)(a + 1.0f + b) * d * rr / (d * d + (a * d + b * rr) * rr) * (double)(T->xco[q + 1] - x0);
+    } else {
+      xx = T->xco[q];
+    }
+    if (xx < x2max) {
+      *costh = 1.0 - 2.0 * xx / x2max;
+      if (ranecu_d(seed, cnt) < (((*costh) * (*costh) + 1.0) * 0.5)) break;
+    }
+  }
+}
+void oracle_graa(const oracle_tables *T, float energy, double *costh, int mat, int index, int *seed2)
+{ i2 s = { seed2[0], seed2[1] }; uint64_t c = 0; graa(T, energy, costh, mat, T->pmax[(index + 1) * MAXMAT + mat], &s, &c); seed2[0] = s.x; seed2[1] = s.y; }
+
+/* ------------------------------------------------------------------------------------------
+ * GCOa (K.cu:1287-1515): Compton, impulse approximation with analytical one-electron profiles.
+ * rn[] is zero-initialised here; the reference leaves entries of inactive shells (U_i >= E)
+ * uninitialised -- unreachable for the bundled materials (max U_i = 4.04 keV < 5 keV cut-off).
+ * ------------------------------------------------------------------------------------------ */
+static inline float shell_pz(float fj0, float aux, float u)
+{ return fj0 * (aux - u * 510998.918f) / (sqrtf(aux + aux + u * u) * 510998.918f); }
+
+static void gcoa(const oracle_tables *T, float *energy, double *costh, int mat, i2 *seed, int pm, uint64_t *cnt)
+{
+  float s, a1, s0, af, ek, ek2, ek3, tau, pzomc = 0.0f, taumin;
+  float rn[MAXSHELLS];
+  double cdt1;
+  int i, nosc = T->noscco[mat];
+  const float E = *energy;
+  memset(rn, 0, sizeof rn);
+  ek = E * 1.956951306108245e-6f;
+  ek2 = ek * 2.f + 1.f;
+  ek3 = ek * ek;
+  taumin = 1.f / ek2;
+  a1 = m_logf(ek2, pm);
+  s0 = 0.0f;
+  for (i = 0; i < nosc; i++) {
+    float t = T->uico[mat + i * MAXMAT];
+    if (t < E) {
+      float aux = E * (E - t) * 2.f;
+      pzomc = shell_pz(T->fj0[mat + i * MAXMAT], aux, t);
+      if (pzomc > 0.0f) t = (0.707106781186545f + pzomc * 1.4142135623731f) * (0.707106781186545f + pzomc * 1.4142135623731f);
+      else t = (0.707106781186545f - pzomc * 1.4142135623731f) * (0.707106781186545f - pzomc * 1.4142135623731f);
+      t = 0.5f * m_expf(0.5f - t, pm);
+      if (pzomc > 0.0f) t = 1.0f - t;
+      s0 += T->fco[mat + i * MAXMAT] * t;
+    }
+  }
+  do {
+    if (ranecu(seed, cnt) * (a1 + 2. * ek * (ek + 1.f) * taumin * taumin) < a1)
+      tau = m_powf(taumin, ranecu(seed, cnt), pm);
+    else
+      tau = sqrtf(1.f + ranecu(seed, cnt) * (taumin * taumin - 1.f));
+    cdt1 = (double)(1.f - tau) / (((double)tau) * ((double)E) * 1.956951306108245e-6);
+    if (cdt1 > 2.0) cdt1 = 1.99999999;
+    s = 0.0f;
+    for (i = 0; i < nosc; i++) {
+      float t = T->uico[mat + i * MAXMAT];
+      if (t < E) {
+        float aux = E * (E - t) * ((float)cdt1);
+        if ((aux > 1.0e-12f) || (t > 1.0e-12f)) pzomc = shell_pz(T->fj0[mat + i * MAXMAT], aux, t);
+        else pzomc = 0.002f;
+        t = pzomc * 1.4142135623731f;
+        if (pzomc > 0.0f) t = 0.5f - (t + 0.70710678118654502f) * (t + 0.70710678118654502f);
+        else t = 0.5f - (0.70710678118654502f - t) * (0.70710678118654502f - t);
+        t = 0.5f * m_expf(t, pm);
+        if (pzomc > 0.0f) t = 1.0f - t;
+        s += T->fco[mat + i * MAXMAT] * t;
+        rn[i] = t;
+      }
+    }
+  } while ((ranecu(seed, cnt) * s0) > (s * (1.0f + tau * ((ek3 - ek2 - 1.0f) + tau * (ek2 + tau * ek3))) / (ek3 * tau * (tau * tau + 1.0f))));
+  *costh = 1.0 - cdt1;
+  for (;;) {
+    float t = s * ranecu(seed, cnt);
+    float pac = 0.0f;
+    int ishell = nosc - 1;
+    for (i = 0; i < (nosc - 1); i++) {
+      pac += T->fco[mat + i * MAXMAT] * rn[i];
+      if (pac > t) { ishell = i; break; }
+    }
+    t = ranecu(seed, cnt) * rn[ishell];
+    if (t < 0.5f) pzomc = (0.70710678118654502f - sqrtf(0.5f - m_logf(t + t, pm))) / (T->fj0[mat + ishell * MAXMAT] * 1.4142135623731f);
+    else pzomc = (sqrtf(0.5f - m_logf(2.0f - 2.0f * t, pm)) - 0.70710678118654502f) / (T->fj0[mat + ishell * MAXMAT] * 1.4142135623731f);
+    if (pzomc < -1.0f) continue;
+    t = tau * (tau - (*costh) * 2.f) + 1.f;      /* double expression rounded to float on assignment */
+    if (t > 1.0e-20f) af = sqrtf(t) * (tau * (tau - ((float)(*costh))) / t + 1.f);
+    else af = 0.00200f;
+    if (af > 0.0f) t = af * 0.2f + 1.f; else t = 1.f - af * 0.2f;
+    {
+      float pzc = (pzomc < 0.2f) ? pzomc : 0.2f;
+      pzc = (pzc > -0.2f) ? pzc : -0.2f;
+      if (ranecu(seed, cnt) * t < (af * pzc + 1.f)) break;
+    }
+  }
+  {
+    float t = pzomc * pzomc;
+    float b1 = 1.f - t * tau * tau;
+    float b2 = 1.f - t * tau * ((float)(*costh));
+    float r = sqrtf(fabsf(b2 * b2 - b1 * (1.0f - t)));
+    if (pzomc < 0.0f) r *= -1.0f;
+    t = (tau / b1) * (b2 + r);
+    if (t > 1.0f) t = 1.0f;
+    *energy = E * t;
+  }
+}
+void oracle_gcoa(const oracle_tables *T, float *energy, double *costh, int mat, int *seed2, int math_mode)
+{ i2 s = { seed2[0], seed2[1] }; uint64_t c = 0; gcoa(T, energy, costh, mat, &s, math_mode, &c); seed2[0] = s.x; seed2[1] = s.y; }
+void oracle_source(const oracle_tables *T, int num_p, int *seed2, float *pos3, float *dir3, float *energy, int *absvox, int math_mode)
+{
+  i2 s = { seed2[0], seed2[1] }; uint64_t c = 0; f3 p, d;
+  *absvox = 1;
+  source(T, (const src_t *)T->source_data + num_p, (const det_t *)T->detector_data + num_p, &p, &d, energy, &s, absvox, math_mode, &c);
+  pos3[0] = p.x; pos3[1] = p.y; pos3[2] = p.z; dir3[0] = d.x; dir3[1] = d.y; dir3[2] = d.z; seed2[0] = s.x; seed2[1] = s.y;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * tally_image (K.cu:482-604), CPU branches (:553-565 rotated detector, :589-600 detector at +Y)
+ * ------------------------------------------------------------------------------------------ */
+static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state, uint64_t *image, const src_t *S, const det_t *D,
+                        oracle_counters *C)
+{
+  float dist, rot;
+  C->tally_calls++;
+  if (D->rotation_flag == 1) {
+    float cosang = dir->x * S->direction.x + (dir->y * S->direction.y + (dir->z * S->direction.z));
+    if (cosang < 0.025f) return;
+    dist = (S->direction.x * (D->center.x - pos->x) + (S->direction.y * (D->center.y - pos->y) + (S->direction.z * (D->center.z - pos->z)))) / cosang;
+    pos->x = pos->x + dist * dir->x;
+    pos->y = pos->y + dist * dir->y;
+    pos->z = pos->z + dist * dir->z;
+    rot = D->rot_inv[0] * pos->x + D->rot_inv[1] * pos->y + D->rot_inv[2] * pos->z;
+    float px = floor((rot - D->corner_min_rotated_to_Y.x) * D->inv_pixel_size_X);
+    if ((px > -0.1f) && (px < (D->num_pixels_x - 0.1f))) {
+      rot = D->rot_inv[6] * pos->x + D->rot_inv[7] * pos->y + D->rot_inv[8] * pos->z;
+      float pz = floor((rot - D->corner_min_rotated_to_Y.z) * D->inv_pixel_size_Z);
+      if ((pz > -0.1f) && (pz < (D->num_pixels_y - 0.1f))) {
+        image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)] += (unsigned long long)(energy * 100.0f + 0.5f);
+        C->tally_hits++;
+      }
+    }
+  } else {
+    if (dir->y < 0.0001f) return;
+    dist = (D->center.y - pos->y) / (dir->y);
+    float px = floor((pos->x + dist * dir->x - D->corner_min_rotated_to_Y.x) * D->inv_pixel_size_X);
+    if ((px > -0.1f) && (px < (D->num_pixels_x - 0.1f))) {
+      float pz = floor((pos->z + dist * dir->z - D->corner_min_rotated_to_Y.z) * D->inv_pixel_size_Z);
+      if ((pz > -0.1f) && (pz < (D->num_pixels_y - 0.1f))) {
+        image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)] += (unsigned long long)(energy * 100.0f + 0.5f);
+        C->tally_hits++;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * track_particles (K.cu:120-384): one batch of `hpt` histories
+ * ------------------------------------------------------------------------------------------ */
+static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, int seed_input, uint64_t *image, int pm, oracle_counters *C)
+{
+  const src_t *S = (const src_t *)T->source_data + num_p;
+  const det_t *D = (const det_t *)T->detector_data + num_p;
+  const float *vox = T->voxel_mat_dens, *Wt = T->mfp_woodcock, *A = T->mfp_a, *B = T->mfp_b;
+  f3 pos, dir;
+  float energy, step, prob, randno, mfp_density, mfpW;
+  float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+  i2 seed;
+  int index, mat = 0, mat_old, scatter_state;
+  init_prng(batch, hpt, seed_input, &seed);
+  for (; hpt > 0; hpt--) {
+    int absvox = 1;
+    C->histories++;
+    source(T, S, D, &pos, &dir, &energy, &seed, &absvox, pm, &C->rng);
+    scatter_state = 0;
+    index = (int)((energy - T->e0) * T->ide + 0.00001f);
+    mfpW = Wt[2 * index] + energy * Wt[2 * index + 1];
+    C->woodcock_reads++;
+    mat_old = -1;
+    for (;;) {
+      float dens = 0.f;
+      if (absvox < 0) break;
+      do {
+        step = -(mfpW)*m_logf(ranecu(&seed, &C->rng), pm);
+        C->steps++;
+        pos.x += step * dir.x;
+        pos.y += step * dir.y;
+        pos.z += step * dir.z;
+        absvox = locate_voxel(T, &pos);
+        if (absvox < 0) break;
+        C->voxel_reads++;
+        mat = (int)(vox[2 * (size_t)absvox] - 1);
+        dens = vox[2 * (size_t)absvox + 1];
+        if (mat != mat_old) {
+          const float *a = A + 3 * ((size_t)index * MAXMAT + mat), *b = B + 3 * ((size_t)index * MAXMAT + mat);
+          ax = a[0]; ay = a[1]; az = a[2]; bx = b[0]; by = b[1]; bz = b[2];
+          mat_old = mat;
+          C->mfp_reads++;
+        }
+        mfp_density = mfpW * dens;
+        prob = 1.0f - mfp_density * (ax + energy * bx);
+        randno = ranecu(&seed, &C->rng);
+      } while (randno < prob);
+      if (absvox < 0) break;
+      prob += mfp_density * (ay + energy * by);
+      if (randno < prob) {
+        double costh;
+        C->compton++;
+        gcoa(T, &energy, &costh, mat, &seed, pm, &C->rng);
+        rotate_dir(&dir, costh, 6.28318530717958647693 * ranecu_d(&seed, &C->rng), pm);
+        index = (int)((energy - T->e0) * T->ide + 0.00001f);
+        if (index > -1) {
+          mfpW = Wt[2 * index] + energy * Wt[2 * index + 1];
+          C->woodcock_reads++;
+          mat_old = -2;
+          scatter_state = (scatter_state == 0) ? 1 : 3;
+        }
+      } else {
+        prob += mfp_density * (az + energy * bz);
+        if (randno < prob) {
+          double costh;
+          C->rayleigh++;
+          graa(T, energy, &costh, mat, T->pmax[(index + 1) * MAXMAT + mat], &seed, &C->rng);
+          rotate_dir(&dir, costh, 6.28318530717958647693 * ranecu_d(&seed, &C->rng), pm);
+          scatter_state = (scatter_state == 0) ? 2 : 3;
+        } else {
+          C->photo++;
+          index = -11;
+        }
+      }
+      if (index < 0) break;
+    }
+    if (index > -1) tally_image(energy, &pos, &dir, scatter_state, image, S, D, C);
+  }
+}
+
+static void add_counters(oracle_counters *a, const oracle_counters *b)
+{
+  a->histories += b->histories; a->steps += b->steps; a->voxel_reads += b->voxel_reads; a->mfp_reads += b->mfp_reads;
+  a->woodcock_reads += b->woodcock_reads; a->compton += b->compton; a->rayleigh += b->rayleigh; a->photo += b->photo;
+  a->rng += b->rng; a->tally_calls += b->tally_calls; a->tally_hits += b->tally_hits;
+}
+
+int oracle_track(const oracle_tables *T, int num_p, int seed_input, int batch0, int nbatches, int hpt, uint64_t *image, int math_mode,
+                 int n_threads, oracle_counters *counters)
+{
+  const det_t *D = (const det_t *)T->detector_data + num_p;
+  const size_t nimg = (size_t)4 * D->total_num_pixels;
+  oracle_counters total;
+  memset(&total, 0, sizeof total);
+  if (n_threads <= 1) {
+    int b;
+    for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &total);
+  } else {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+    {
+      uint64_t *priv = (uint64_t *)calloc(nimg, sizeof(uint64_t));
+      oracle_counters c;
+      int b;
+      size_t k;
+      memset(&c, 0, sizeof c);
+#pragma omp for schedule(dynamic, 16)
+      for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, priv, math_mode, &c);
+#pragma omp critical
+      {
+        for (k = 0; k < nimg; k++) image[k] += priv[k];
+        add_counters(&total, &c);
+      }
+      free(priv);
+    }
+#else
+    int b;
+    for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &total);
+#endif
+  }
+  if (counters) add_counters(counters, &total);
+  return 0;
+}

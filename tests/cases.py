@@ -1,0 +1,79 @@
+"""Shared test-case builder (test infrastructure): small geometries + `.in` files on disk.
+
+Material numbering in the reduced cases follows the reference's 22-material order; materials
+without a data fixture get header-only stubs (only their density line is ever read).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLDEN = ROOT / "tests" / "golden"
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+geometry = pkg.geometry
+simulation = pkg.simulation
+materials = pkg.materials
+
+CACHE = Path(os.environ.get("MCGPU_TEST_CACHE", "/tmp/mcgpu_amd_test_cache"))
+
+
+def material_files():
+    return materials.resolve_material_files([GOLDEN / "materials"], CACHE / "materials")
+
+
+def spectrum_file():
+    return GOLDEN / "spectra" / "125kVp_0.89mmTi_varian_norm.spc"
+
+
+# name -> (geometry factory, simulation kwargs).  Detector reduced 8x (231x96 px of 3.104 mm) so that
+# integer tallies make small fixtures; apertures / distances are the reference defaults.
+def _catphan_small():
+    return geometry.MCCatPhan604Geometry(shape=(64, 64, 64), image_spacing=(4.0, 4.0, 4.0), scale=0.25)
+
+
+def _water_box():
+    return geometry.MCBoxGeometry(shape=(24, 24, 24), image_spacing=(10.0, 10.0, 10.0), material="h2o")
+
+
+def _air():
+    return geometry.MCAirGeometry()
+
+
+def _slab_nonsquare():
+    # non-square slice (exercises the rot90 / swapped-spacing rule and the off-centre source)
+    g = geometry.MCBoxGeometry(shape=(30, 20, 16), image_spacing=(8.0, 10.0, 12.0), material="h2o")
+    g.materials[8:20, 5:15, 4:12] = materials.material_number("bone_050")
+    g.densities[8:20, 5:15, 4:12] = 1.4
+    g.materials[22:28, 2:8, :] = materials.material_number("teflon")
+    g.densities[22:28, 2:8, :] = 2.16
+    return g
+
+
+SMALL_DET = dict(n_detector_pixels=(231, 96), detector_size=(717.024, 297.984))
+CASES = {
+    "air": (_air, dict(n_projections=1, n_histories=300_000, **SMALL_DET)),
+    "water": (_water_box, dict(n_projections=1, n_histories=150_000, **SMALL_DET)),
+    "catphan64": (_catphan_small, dict(n_projections=1, n_histories=300_000, **SMALL_DET)),
+    "catphan64_ct": (_catphan_small, dict(n_projections=4, angle_between_projections=90.0, n_histories=60_000, **SMALL_DET)),
+    "slab_angles": (_slab_nonsquare, dict(projection_angles=[270.0, 300.5, 45.25], n_histories=60_000, **SMALL_DET)),
+}
+
+
+def build_case(name: str, out_dir, compress=False, **overrides) -> Path:
+    """Write geometry + input file for case `name` under `out_dir`; returns the `.in` path."""
+    factory, kwargs = CASES[name]
+    kwargs = dict(kwargs)
+    kwargs.update(overrides)
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    sim = simulation.MCSimulation(factory(), material_files(), spectrum_file(), **kwargs)
+    return sim.prepare_simulation(out_dir, compress_geometry=compress)
