@@ -1,0 +1,555 @@
+// engine.cpp -- device upload, launch and the C ABI (include/mcgpu_amd.h) of the MC CBCT engine.
+//
+// Replaces init_CUDA_device (docker/mcgpu/MC-GPU_v1.3.cu:2454-2724) and the per-projection driver of
+// main() (:667-1056).  Compiled with hipcc; every HIP call lives here or in the kernel TUs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/mcgpu_amd.h"
+#include "device_model.hpp"
+
+namespace mcgpu {
+
+hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t stream);
+hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
+hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
+hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+  g_last_error = msg.find("ERROR") == std::string::npos ? "!!ERROR!! " + msg : msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) throw Error(-1, std::string("!!HIP ERROR!! ") + #expr + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct DeviceModel {
+  int device_id = -1;
+  void* vol = nullptr;
+  size_t vol_bytes = 0;
+  int vol_kind = kVolU8, palette_size = 0;
+  float* palette = nullptr;
+  float *woodcock = nullptr, *mfp = nullptr;
+  float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
+  unsigned char *itl = nullptr, *itu = nullptr;
+  float *fco = nullptr, *uico = nullptr, *fj0 = nullptr;
+  int* noscco = nullptr;
+  float *espc = nullptr, *cutoff = nullptr;
+  short* alias = nullptr;
+  int nmat = 0;
+  int compact_of[kMaxMaterials];
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool timed = false;
+  int num_cus = 256;
+  std::vector<void*> allocations;
+
+  template <typename T>
+  T* put(const std::vector<T>& host) {
+    void* d = nullptr;
+    const size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&d, bytes));
+    allocations.push_back(d);
+    if (!host.empty()) HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return (T*)d;
+  }
+  void release() {
+    for (void* p : allocations) (void)hipFree(p);
+    allocations.clear();
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (ev_stop) (void)hipEventDestroy(ev_stop);
+    ev_start = ev_stop = nullptr;
+  }
+};
+
+}  // namespace
+}  // namespace mcgpu
+
+struct mcgpu_ctx {
+  mcgpu::HostModel host;
+  mcgpu::DeviceModel dev;
+  bool has_device = false;
+  std::map<std::string, std::vector<unsigned char>> table_cache;
+};
+
+namespace mcgpu {
+namespace {
+
+// Build the palette-compressed volume and the compact-material tables and upload everything.
+void upload_model(mcgpu_ctx& C, int device_id) {
+  const HostModel& H = C.host;
+  DeviceModel& D = C.dev;
+  HIP_TRY(hipSetDevice(device_id));
+  D.device_id = device_id;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  D.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+  // compact material numbering
+  D.nmat = 0;
+  for (int m = 0; m < kMaxMaterials; ++m) D.compact_of[m] = H.mat.used[m] ? D.nmat++ : -1;
+  const int nmat = D.nmat, nv = H.mat.num_values;
+
+  // ---- volume -> palette indices
+  const size_t nvox = H.voxels.count();
+  std::unordered_map<uint64_t, int> index_of;
+  std::vector<float> palette;  // {density, bits(mat_c)}
+  std::vector<uint16_t> idx16(nvox);
+  bool overflow = false;
+  {
+    uint64_t last_key = ~0ull;
+    int last_idx = -1;
+    for (size_t i = 0; i < nvox; ++i) {
+      uint32_t db;
+      memcpy(&db, &H.voxels.density[i], 4);
+      const uint64_t key = ((uint64_t)H.voxels.material[i] << 32) | db;
+      if (key != last_key) {
+        auto it = index_of.find(key);
+        if (it == index_of.end()) {
+          if (index_of.size() >= 65536) { overflow = true; break; }
+          const int mc = D.compact_of[H.voxels.material[i] - 1];
+          if (mc < 0) throw Error(-2, "!!ERROR!! A voxel uses material " + std::to_string((int)H.voxels.material[i]) + " but no data file was given for it.");
+          float mcf;
+          memcpy(&mcf, &mc, 4);
+          last_idx = (int)index_of.size();
+          index_of.emplace(key, last_idx);
+          palette.push_back(H.voxels.density[i]);
+          palette.push_back(mcf);
+        } else {
+          last_idx = it->second;
+        }
+        last_key = key;
+      }
+      idx16[i] = (uint16_t)last_idx;
+    }
+  }
+  if (overflow) {
+    D.vol_kind = kVolRaw;
+    std::vector<float> raw(2 * nvox);
+    for (size_t i = 0; i < nvox; ++i) {
+      const int mc = D.compact_of[H.voxels.material[i] - 1];
+      if (mc < 0) throw Error(-2, "!!ERROR!! A voxel uses a material without data file.");
+      raw[2 * i] = H.voxels.density[i];
+      memcpy(&raw[2 * i + 1], &mc, 4);
+    }
+    D.vol = D.put(raw);
+    D.vol_bytes = raw.size() * 4;
+    D.palette_size = 0;
+    D.palette = D.put(std::vector<float>(2, 0.f));
+  } else if (index_of.size() <= 256) {
+    D.vol_kind = kVolU8;
+    std::vector<uint8_t> idx8(nvox);
+    for (size_t i = 0; i < nvox; ++i) idx8[i] = (uint8_t)idx16[i];
+    D.vol = D.put(idx8);
+    D.vol_bytes = nvox;
+    D.palette_size = (int)index_of.size();
+    D.palette = D.put(palette);
+  } else {
+    D.vol_kind = kVolU16;
+    D.vol = D.put(idx16);
+    D.vol_bytes = nvox * 2;
+    D.palette_size = (int)index_of.size();
+    D.palette = D.put(palette);
+  }
+
+  // ---- cross-section records
+  std::vector<float> wood(2 * (size_t)nv), rec(8 * (size_t)nv * nmat, 0.f);
+  for (int i = 0; i < nv; ++i) { wood[2 * i] = H.mat.woodcock[i].x; wood[2 * i + 1] = H.mat.woodcock[i].y; }
+  for (int i = 0; i < nv; ++i)
+    for (int m = 0; m < kMaxMaterials; ++m) {
+      const int mc = D.compact_of[m];
+      if (mc < 0) continue;
+      float* r = &rec[8 * ((size_t)i * nmat + mc)];
+      const Float3& a = H.mat.a[(size_t)i * kMaxMaterials + m];
+      const Float3& b = H.mat.b[(size_t)i * kMaxMaterials + m];
+      r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
+      r[6] = H.mat.pmax[(size_t)(i + 1) * kMaxMaterials + m];
+      r[7] = 0.f;
+    }
+  D.woodcock = D.put(wood);
+  D.mfp = D.put(rec);
+  std::vector<float> xco(kRayleighPoints * nmat), pco(xco), aco(xco), bco(xco);
+  std::vector<unsigned char> itl(kRayleighPoints * nmat), itu(itl);
+  std::vector<float> fco(kMaxShells * nmat, 0.f), uico(fco), fj0(fco);
+  std::vector<int> nosc(std::max(nmat, 1), 0);
+  for (int m = 0; m < kMaxMaterials; ++m) {
+    const int mc = D.compact_of[m];
+    if (mc < 0) continue;
+    for (int i = 0; i < kRayleighPoints; ++i) {
+      xco[mc * kRayleighPoints + i] = H.mat.xco[m * kRayleighPoints + i];
+      pco[mc * kRayleighPoints + i] = H.mat.pco[m * kRayleighPoints + i];
+      aco[mc * kRayleighPoints + i] = H.mat.aco[m * kRayleighPoints + i];
+      bco[mc * kRayleighPoints + i] = H.mat.bco[m * kRayleighPoints + i];
+      itl[mc * kRayleighPoints + i] = H.mat.itlco[m * kRayleighPoints + i];
+      itu[mc * kRayleighPoints + i] = H.mat.ituco[m * kRayleighPoints + i];
+    }
+    for (int s = 0; s < kMaxShells; ++s) {
+      fco[s * nmat + mc] = H.mat.fco[m + s * kMaxMaterials];
+      uico[s * nmat + mc] = H.mat.uico[m + s * kMaxMaterials];
+      fj0[s * nmat + mc] = H.mat.fj0[m + s * kMaxMaterials];
+    }
+    nosc[mc] = H.mat.noscco[m];
+  }
+  D.xco = D.put(xco); D.pco = D.put(pco); D.aco = D.put(aco); D.bco = D.put(bco);
+  D.itl = D.put(itl); D.itu = D.put(itu);
+  D.fco = D.put(fco); D.uico = D.put(uico); D.fj0 = D.put(fj0);
+  D.noscco = D.put(nosc);
+  D.espc = D.put(std::vector<float>(H.spectrum.espc, H.spectrum.espc + kMaxSpectrumBins));
+  D.cutoff = D.put(std::vector<float>(H.spectrum.cutoff, H.spectrum.cutoff + kMaxSpectrumBins));
+  D.alias = D.put(std::vector<short>(H.spectrum.alias, H.spectrum.alias + kMaxSpectrumBins));
+  HIP_TRY(hipEventCreate(&D.ev_start));
+  HIP_TRY(hipEventCreate(&D.ev_stop));
+  HIP_TRY(hipDeviceSynchronize());
+}
+
+TrackArgs make_args(const mcgpu_ctx& C, int p) {
+  const HostModel& H = C.host;
+  const DeviceModel& D = C.dev;
+  TrackArgs A;
+  memset(&A, 0, sizeof A);
+  A.vol = D.vol; A.palette = D.palette; A.vol_kind = D.vol_kind; A.palette_size = D.palette_size;
+  A.nx = H.voxels.n[0]; A.ny = H.voxels.n[1]; A.nz = H.voxels.n[2]; A.nxy = A.nx * A.ny;
+  for (int k = 0; k < 3; ++k) { A.inv_vs[k] = H.voxels.inv_voxel_size[k]; A.bbox[k] = H.voxels.size_bbox[k]; }
+  A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat;
+  A.woodcock = D.woodcock; A.mfp = D.mfp;
+  A.xco = D.xco; A.pco = D.pco; A.aco = D.aco; A.bco = D.bco; A.itl = D.itl; A.itu = D.itu;
+  A.fco = D.fco; A.uico = D.uico; A.fj0 = D.fj0; A.noscco = D.noscco;
+  A.nbins = H.spectrum.num_bins; A.espc = D.espc; A.cutoff = D.cutoff; A.alias = D.alias;
+  A.src = H.source[p]; A.det = H.detector[p];
+  A.stream_key = (unsigned)p;
+  A.service_threshold = 16;
+  return A;
+}
+
+void require(bool ok, int code, const char* msg) { if (!ok) throw Error(code, msg); }
+
+const void* host_table(mcgpu_ctx& C, const std::string& name, size_t& bytes) {
+  HostModel& H = C.host;
+  auto cache = [&](const void* p, size_t n) -> const void* {
+    auto& v = C.table_cache[name];
+    v.assign((const unsigned char*)p, (const unsigned char*)p + n);
+    bytes = n;
+    return v.data();
+  };
+#define DIRECT(vec) do { bytes = (vec).size() * sizeof((vec)[0]); return (const void*)(vec).data(); } while (0)
+  if (name == "source_data") DIRECT(H.source);
+  if (name == "detector_data") DIRECT(H.detector);
+  if (name == "mfp_woodcock") DIRECT(H.mat.woodcock);
+  if (name == "mfp_a") DIRECT(H.mat.a);
+  if (name == "mfp_b") DIRECT(H.mat.b);
+  if (name == "xco") DIRECT(H.mat.xco);
+  if (name == "pco") DIRECT(H.mat.pco);
+  if (name == "aco") DIRECT(H.mat.aco);
+  if (name == "bco") DIRECT(H.mat.bco);
+  if (name == "pmax") DIRECT(H.mat.pmax);
+  if (name == "itlco") DIRECT(H.mat.itlco);
+  if (name == "ituco") DIRECT(H.mat.ituco);
+  if (name == "fco") DIRECT(H.mat.fco);
+  if (name == "uico") DIRECT(H.mat.uico);
+  if (name == "fj0") DIRECT(H.mat.fj0);
+#undef DIRECT
+  if (name == "noscco") return cache(H.mat.noscco, sizeof H.mat.noscco);
+  if (name == "espc") return cache(H.spectrum.espc, sizeof H.spectrum.espc);
+  if (name == "espc_cutoff") return cache(H.spectrum.cutoff, sizeof H.spectrum.cutoff);
+  if (name == "espc_alias") return cache(H.spectrum.alias, sizeof H.spectrum.alias);
+  if (name == "density_max") return cache(H.voxels.density_max, sizeof H.voxels.density_max);
+  if (name == "density_nominal") return cache(H.mat.density_nominal, sizeof H.mat.density_nominal);
+  if (name == "voxel_size") return cache(H.voxels.voxel_size, sizeof H.voxels.voxel_size);
+  if (name == "inv_voxel_size") return cache(H.voxels.inv_voxel_size, sizeof H.voxels.inv_voxel_size);
+  if (name == "size_bbox") return cache(H.voxels.size_bbox, sizeof H.voxels.size_bbox);
+  if (name == "voxel_mat_dens") {  // reference layout: float2 {material + 0.0001f, density} (MC-GPU_v1.3.cu:2135-2136)
+    auto& v = C.table_cache[name];
+    const size_t n = H.voxels.count();
+    v.resize(n * 8);
+    float* f = (float*)v.data();
+    for (size_t i = 0; i < n; ++i) { f[2 * i] = (float)(H.voxels.material[i]) + 0.0001f; f[2 * i + 1] = H.voxels.density[i]; }
+    bytes = v.size();
+    return v.data();
+  }
+  return nullptr;
+}
+
+}  // namespace
+}  // namespace mcgpu
+
+using namespace mcgpu;
+
+#define ABI_BEGIN try {
+#define ABI_END                                               \
+  }                                                           \
+  catch (const Error& e) { return set_error(e.code, e.what()); } \
+  catch (const std::exception& e) { return set_error(-2, e.what()); } \
+  catch (...) { return set_error(-2, "unknown failure"); }
+
+extern "C" {
+
+int mcgpu_abi_version(void) { return 1; }
+const char* mcgpu_last_error(void) { return g_last_error.c_str(); }
+
+int mcgpu_create(const char* input_path, int device_id, mcgpu_ctx** out) {
+  ABI_BEGIN
+  require(input_path && out, -1, "!!ERROR!! mcgpu_create: null argument");
+  std::unique_ptr<mcgpu_ctx> c(new mcgpu_ctx);
+  load_model(input_path, c->host);
+  if (device_id >= 0) {
+    upload_model(*c, device_id);
+    c->has_device = true;
+  }
+  *out = c.release();
+  return 0;
+  ABI_END
+}
+
+void mcgpu_destroy(mcgpu_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->has_device) {
+    (void)hipSetDevice(ctx->dev.device_id);
+    ctx->dev.release();
+  }
+  delete ctx;
+}
+
+int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
+  ABI_BEGIN
+  require(ctx && key && value, -1, "!!ERROR!! mcgpu_config_i64: null argument");
+  const SimConfig& c = ctx->host.cfg;
+  const std::string k(key);
+  if (k == "total_histories") *value = (long long)c.total_histories;
+  else if (k == "seed") *value = c.seed;
+  else if (k == "gpu_id") *value = c.gpu_id;
+  else if (k == "threads_per_block") *value = c.threads_per_block;
+  else if (k == "histories_per_thread") *value = c.histories_per_thread;
+  else if (k == "num_projections") *value = c.num_projections;
+  else if (k == "enable_specific_angles") *value = c.enable_specific_angles;
+  else if (k == "flag_material_dose") *value = c.flag_material_dose;
+  else if (k == "num_voxels_x") *value = ctx->host.voxels.n[0];
+  else if (k == "num_voxels_y") *value = ctx->host.voxels.n[1];
+  else if (k == "num_voxels_z") *value = ctx->host.voxels.n[2];
+  else if (k == "num_pixels_x") *value = ctx->host.detector[0].nx;
+  else if (k == "num_pixels_z") *value = ctx->host.detector[0].nz;
+  else if (k == "num_energy_values") *value = ctx->host.mat.num_values;
+  else if (k == "num_spectrum_bins") *value = ctx->host.spectrum.num_bins;
+  else if (k == "num_materials_used") { int n = 0; for (int m = 0; m < kMaxMaterials; ++m) n += ctx->host.mat.used[m]; *value = n; }
+  else if (k == "palette_size") *value = ctx->dev.palette_size;
+  else if (k == "volume_kind") *value = ctx->dev.vol_kind;
+  else if (k == "volume_bytes_device") *value = (long long)ctx->dev.vol_bytes;
+  else if (k == "num_cus") *value = ctx->dev.num_cus;
+  else return set_error(-2, std::string("unknown integer key: ") + key);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_config_f64(const mcgpu_ctx* ctx, const char* key, double* value) {
+  ABI_BEGIN
+  require(ctx && key && value, -1, "!!ERROR!! mcgpu_config_f64: null argument");
+  const SimConfig& c = ctx->host.cfg;
+  const std::string k(key);
+  if (k == "D_angle") *value = c.D_angle;
+  else if (k == "initial_angle") *value = c.initial_angle;
+  else if (k == "angularROI_0") *value = c.angularROI_0;
+  else if (k == "angularROI_1") *value = c.angularROI_1;
+  else if (k == "SRotAxisD") *value = c.SRotAxisD;
+  else if (k == "vertical_translation") *value = c.vertical_translation;
+  else if (k == "mean_energy_spectrum") *value = ctx->host.spectrum.mean_energy;
+  else if (k == "e0") *value = ctx->host.mat.e0;
+  else if (k == "ide") *value = ctx->host.mat.ide;
+  else return set_error(-2, std::string("unknown float key: ") + key);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_host_table(mcgpu_ctx* ctx, const char* name, const void** data, size_t* bytes) {
+  ABI_BEGIN
+  require(ctx && name && data && bytes, -1, "!!ERROR!! mcgpu_host_table: null argument");
+  size_t n = 0;
+  const void* p = host_table(*ctx, name, n);
+  if (!p) return set_error(-2, std::string("unknown table: ") + name);
+  *data = p;
+  *bytes = n;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_projection_file_name(const mcgpu_ctx* ctx, int p, char* buf, size_t buf_bytes) {
+  ABI_BEGIN
+  require(ctx && buf && p >= 0 && p < ctx->host.cfg.num_projections, -1, "!!ERROR!! mcgpu_projection_file_name: bad argument");
+  const std::string s = projection_file_name(ctx->host, p);
+  require(s.size() + 1 <= buf_bytes, -2, "!!ERROR!! mcgpu_projection_file_name: buffer too small");
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_image_words(const mcgpu_ctx* ctx, size_t* words) {
+  ABI_BEGIN
+  require(ctx && words, -1, "!!ERROR!! mcgpu_image_words: null argument");
+  *words = (size_t)4 * ctx->host.detector[0].total_pixels;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_launch_shape(unsigned long long histories, int threads_per_block, int histories_per_thread, int* blocks, int* hpt_out,
+                       unsigned long long* total_histories) {
+  ABI_BEGIN
+  require(threads_per_block > 0 && histories_per_thread > 0, -2, "!!ERROR!! mcgpu_launch_shape: bad argument");
+  const LaunchShape L = reference_launch_shape(histories, threads_per_block, histories_per_thread);
+  if (blocks) *blocks = L.blocks;
+  if (hpt_out) *hpt_out = L.hpt;
+  if (total_histories) *total_histories = L.total_histories;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_advance_seed(int batch_number, unsigned long long total_histories, int seed) {
+  return ranecu_advance_seed(batch_number, total_histories, seed);
+}
+
+int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned long long first, unsigned long long count, int hpt,
+                            void* image_dev, void* hip_stream) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_launch_projection: the context has no device (created with device_id < 0)");
+  require(p >= 0 && p < ctx->host.cfg.num_projections, -1, "!!ERROR!! mcgpu_launch_projection: projection index out of range");
+  require(image_dev != nullptr, -1, "!!ERROR!! mcgpu_launch_projection: null image buffer");
+  require(mode == MCGPU_MODE_FAST || mode == MCGPU_MODE_COMPAT, -1, "!!ERROR!! mcgpu_launch_projection: unknown mode");
+  DeviceModel& D = ctx->dev;
+  HIP_TRY(hipSetDevice(D.device_id));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  TrackArgs A = make_args(*ctx, p);
+  A.image = (unsigned long long*)image_dev;
+  A.seed = seed; A.hpt = hpt; A.first = first; A.count = count;
+  HIP_TRY(hipEventRecord(D.ev_start, stream));
+  if (count > 0) {
+    if (mode == MCGPU_MODE_COMPAT) {
+      require(hpt > 0, -2, "!!ERROR!! mcgpu_launch_projection: histories per thread must be positive in COMPAT mode");
+      require(seed > 0 && seed < 2147483399, -2, "!!ERROR!! mcgpu_launch_projection: RANECU seed out of range");
+      const unsigned long long blocks = (count + 255) / 256;
+      require(blocks <= 0x7fffffffULL, -2, "!!ERROR!! mcgpu_launch_projection: too many batches");
+      HIP_TRY(launch_track_compat(A, (int)blocks, stream));
+    } else {
+      const unsigned long long want = (count + 255) / 256;
+      const unsigned long long resident = (unsigned long long)D.num_cus * 8ULL;
+      HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
+    }
+  }
+  HIP_TRY(hipEventRecord(D.ev_stop, stream));
+  D.timed = true;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_last_kernel_ms(mcgpu_ctx* ctx, float* ms) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && ms, -1, "!!ERROR!! mcgpu_last_kernel_ms: bad argument");
+  require(ctx->dev.timed, -1, "!!ERROR!! mcgpu_last_kernel_ms: nothing launched yet");
+  HIP_TRY(hipEventSynchronize(ctx->dev.ev_stop));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->dev.ev_start, ctx->dev.ev_stop));
+  return 0;
+  ABI_END
+}
+
+int mcgpu_clear_image(mcgpu_ctx* ctx, void* image_dev, void* hip_stream) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && image_dev, -1, "!!ERROR!! mcgpu_clear_image: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  HIP_TRY(hipMemsetAsync(image_dev, 0, (size_t)32 * ctx->host.detector[0].total_pixels, (hipStream_t)hip_stream));
+  return 0;
+  ABI_END
+}
+
+int mcgpu_run_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned long long first, unsigned long long count, int hpt,
+                         uint64_t* image_host, double* kernel_seconds, unsigned long long* histories_done) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && image_host, -1, "!!ERROR!! mcgpu_run_projection: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  const size_t bytes = (size_t)32 * ctx->host.detector[0].total_pixels;
+  void* img = nullptr;
+  HIP_TRY(hipMalloc(&img, bytes));
+  int rc = 0;
+  try {
+    HIP_TRY(hipMemset(img, 0, bytes));
+    rc = mcgpu_launch_projection(ctx, p, mode, seed, first, count, hpt, img, nullptr);
+    if (rc == 0) {
+      float ms = 0.f;
+      rc = mcgpu_last_kernel_ms(ctx, &ms);
+      if (kernel_seconds) *kernel_seconds = ms * 1e-3;
+      HIP_TRY(hipMemcpy(image_host, img, bytes, hipMemcpyDeviceToHost));
+      if (histories_done) *histories_done = (mode == MCGPU_MODE_COMPAT) ? count * (unsigned long long)hpt : count;
+    }
+  } catch (...) {
+    (void)hipFree(img);
+    throw;
+  }
+  (void)hipFree(img);
+  return rc;
+  ABI_END
+}
+
+int mcgpu_write_projection(mcgpu_ctx* ctx, int p, const uint64_t* image_host, unsigned long long total_histories, double seconds,
+                           const char* file_name) {
+  ABI_BEGIN
+  require(ctx && image_host && p >= 0 && p < ctx->host.cfg.num_projections, -1, "!!ERROR!! mcgpu_write_projection: bad argument");
+  require(total_histories > 0, -2, "!!ERROR!! mcgpu_write_projection: zero histories");
+  const std::string name = file_name ? std::string(file_name) : projection_file_name(ctx->host, p);
+  write_projection_ascii(ctx->host, p, image_host, total_histories, seconds, name);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_write_voxel_file(const char* path, const int n[3], const float spacing_cm[3], const uint8_t* material, const float* density,
+                           int gzip) {
+  ABI_BEGIN
+  require(path && n && spacing_cm && material && density, -1, "!!ERROR!! mcgpu_write_voxel_file: null argument");
+  write_voxel_file(path, n, spacing_cm, material, density, gzip != 0);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_kat_rng(mcgpu_ctx* ctx, int mode, int seed, int batch, int hpt, int n, float* out_f32) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && out_f32 && n > 0, -1, "!!ERROR!! mcgpu_kat_rng: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  float* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, (size_t)n * 4));
+  hipError_t e = launch_kat_rng(mode, seed, batch, hpt, n, d, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out_f32, d, (size_t)n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_kat_math(mcgpu_ctx* ctx, int n, const double* x, double* out_log, double* out_exp, double* out_sin, double* out_cos) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && x && out_log && out_exp && out_sin && out_cos && n > 0, -1, "!!ERROR!! mcgpu_kat_math: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  double* d = nullptr;
+  const size_t nb = (size_t)n * 8;
+  HIP_TRY(hipMalloc((void**)&d, 5 * nb));
+  hipError_t e = hipMemcpy(d, x, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_kat_math(n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out_log, d + n, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_exp, d + 2 * n, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_sin, d + 3 * n, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_cos, d + 4 * n, nb, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return 0;
+  ABI_END
+}
+
+}  // extern "C"

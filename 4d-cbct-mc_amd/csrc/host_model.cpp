@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -109,7 +110,7 @@ void set_rot_fan(float* r, double rotX, double rotZ) {
 // Angle that brings direction (u,v) onto +Y by a rotation about Z (:1755-1764, :3370-3376).
 double rot_z_to_plus_y(float u, float v) {
   if ((u * u + v * v) > 1.0e-8) {
-    const double c = acos(u / sqrt(u * u + v * v));  // float expression promoted, as in the reference
+    const double c = acos((double)u / sqrt((double)(u * u + v * v)));  // float sum of squares, double sqrt/divide (C semantics of the reference)
     return (v >= 0.0f) ? 0.5 * kPi - c : 0.5 * kPi - (-c);
   }
   return 0.0;

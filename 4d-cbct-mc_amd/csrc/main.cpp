@@ -1,0 +1,120 @@
+// main.cpp -- drop-in executable `MC-GPU_v1.3.x <input.in>` (docker/mcgpu/MC-GPU_v1.3.cu:377-1214).
+//
+// Same command line, same input/output files and the same progress line on stdout
+// ("<< Simulating Projection i of n >>", parsed by cbctmc/mc/simulation.py:200-219); the word "error"
+// is only ever printed on failure (simulation.py:204 greps for it).  Options after the input file:
+//   --mode fast|compat   kernel personality (default fast)
+//   --gpus N             history-shard every projection over N devices of this node (default 1);
+//                        per-device tallies are summed on the host (integers: order-independent)
+//   --no-output          skip the ASCII projection files (timing runs)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mcgpu_amd.h"
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    printf("\n\n   !!read_input ERROR!! Input file name not given as an execution parameter!! Try again...\n\n");
+    return 255;
+  }
+  int mode = MCGPU_MODE_FAST, ngpu = 1;
+  bool write_out = true;
+  for (int i = 2; i < argc; ++i) {
+    if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = !strcmp(argv[++i], "compat") ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
+    else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--no-output")) write_out = false;
+  }
+  if (ngpu < 1) ngpu = 1;
+  const double t_begin = now_s();
+  printf("\n     *** MC CBCT projection engine for AMD MI355X (MC-GPU v1.3 file contract) ***\n\n    -- INITIALIZATION phase:\n");
+  fflush(stdout);
+  std::vector<mcgpu_ctx*> ctx(ngpu, nullptr);
+  long long gpu_id = 0;
+  for (int g = 0; g < ngpu; ++g) {
+    // single GPU: the input file's GPU number; several: devices 0..N-1
+    int dev = g;
+    if (ngpu == 1) {
+      mcgpu_ctx* probe = nullptr;
+      if (mcgpu_create(argv[1], -1, &probe) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 254; }
+      mcgpu_config_i64(probe, "gpu_id", &gpu_id);
+      mcgpu_destroy(probe);
+      dev = gpu_id > 0 ? (int)gpu_id : 0;
+    }
+    if (mcgpu_create(argv[1], dev, &ctx[g]) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 254; }
+  }
+  long long nproj = 1, hist = 0, seed = 0, tpb = 128, hpt = 150;
+  mcgpu_config_i64(ctx[0], "num_projections", &nproj);
+  mcgpu_config_i64(ctx[0], "total_histories", &hist);
+  mcgpu_config_i64(ctx[0], "seed", &seed);
+  mcgpu_config_i64(ctx[0], "threads_per_block", &tpb);
+  mcgpu_config_i64(ctx[0], "histories_per_thread", &hpt);
+  double d_angle = 0, a0 = 0, roi0 = 0, roi1 = 0;
+  mcgpu_config_f64(ctx[0], "D_angle", &d_angle);
+  mcgpu_config_f64(ctx[0], "initial_angle", &a0);
+  mcgpu_config_f64(ctx[0], "angularROI_0", &roi0);
+  mcgpu_config_f64(ctx[0], "angularROI_1", &roi1);
+  size_t words = 0;
+  mcgpu_image_words(ctx[0], &words);
+  printf("\n    -- INITIALIZATION finished: elapsed time = %.3f s. \n\n\n    -- MONTE CARLO LOOP phase.\n\n", now_s() - t_begin);
+  fflush(stdout);
+
+  int blocks = 1, hpt_eff = (int)hpt;
+  unsigned long long total = (unsigned long long)hist;
+  if (mode == MCGPU_MODE_COMPAT) mcgpu_launch_shape((unsigned long long)hist, (int)tpb, (int)hpt, &blocks, &hpt_eff, &total);
+  std::vector<std::vector<uint64_t>> img(ngpu, std::vector<uint64_t>(words));
+  double t_mc = 0.0;
+  int cur_seed = (int)seed;
+  const double RAD2DEG = 180.0 / 3.14159265358979323846;
+  for (int p = 0; p < (int)nproj; ++p) {
+    const double ang = a0 + p * d_angle;
+    if (nproj != 1 && (ang < roi0 || ang > roi1)) {
+      printf("         << Skipping projection #%d of %d >> Angle %f degrees: outside angular region of interest.\n", p + 1, (int)nproj, ang * RAD2DEG);
+      continue;
+    }
+    if (nproj != 1) printf("\n\n\n   << Simulating Projection %d of %d >> Angle: %lf degrees.\n\n\n", p + 1, (int)nproj, ang * RAD2DEG);
+    fflush(stdout);
+    const double t0 = now_s();
+    // units to shard: batches (compat) or histories (fast)
+    const unsigned long long units = mode == MCGPU_MODE_COMPAT ? (unsigned long long)blocks * (unsigned long long)tpb : total;
+    std::vector<int> rc(ngpu, 0);
+    std::vector<std::string> err(ngpu);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ngpu; ++g)
+      th.emplace_back([&, g]() {
+        const unsigned long long lo = units * g / ngpu, hi = units * (g + 1) / ngpu;
+        rc[g] = mcgpu_run_projection(ctx[g], p, mode, cur_seed, lo, hi - lo, hpt_eff, img[g].data(), nullptr, nullptr);
+        if (rc[g]) err[g] = mcgpu_last_error();
+      });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < ngpu; ++g)
+      if (rc[g]) { printf("\n\n   %s\n\n", err[g].c_str()); return 253; }
+    for (int g = 1; g < ngpu; ++g)
+      for (size_t i = 0; i < words; ++i) img[0][i] += img[g][i];
+    const double dt = now_s() - t0;
+    t_mc += dt;
+    printf("          *** IMAGE TALLY PERFORMANCE REPORT ***\n              CT projection %d of %d\n              Simulated x rays:    %llu\n"
+           "              Simulation time [s]: %.2f\n              Speed [x-rays/s]:    %.2f\n\n", p + 1, (int)nproj, total, dt, dt > 0 ? total / dt : 0.0);
+    if (write_out && mcgpu_write_projection(ctx[0], p, img[0].data(), total, dt, nullptr) != 0) {
+      printf("\n\n   %s\n\n", mcgpu_last_error());
+      return 253;
+    }
+    // next projection gets a disjoint stream set (update_seed_PRNG, MC-GPU_v1.3.cu:869)
+    if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
+    fflush(stdout);
+  }
+  for (auto* c : ctx) mcgpu_destroy(c);
+  const double t_all = now_s() - t_begin;
+  printf("\n\n\n    -- SIMULATION FINISHED!\n\n          >>> Execution time including initialization, transport and report: %.3f s.\n"
+         "          >>> Time spent in the Monte Carlo transport only: %.3f s.\n          >>> Total number of simulated x rays:  %llu\n",
+         t_all, t_mc, total * (unsigned long long)nproj);
+  return 0;
+}

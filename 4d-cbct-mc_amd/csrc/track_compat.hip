@@ -1,0 +1,40 @@
+// track_compat.hip -- COMPAT personality of the photon-history kernel (bit-exact against the CPU oracle).
+// Build with -ffp-contract=off: no fused multiply-add may be formed, every float/double op rounds once.
+#define MC_COMPAT 1
+#include "track_kernel.inc"
+
+namespace mcgpu {
+namespace {
+// Known-answer kernels (mcgpu_kat_rng / mcgpu_kat_math in include/mcgpu_amd.h)
+__global__ void kat_ranecu(int seed, int batch, int hpt, int n, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Rng r;
+  rng_init_batch(r, (unsigned long long)batch, hpt, seed);
+  for (int i = 0; i < n; ++i) out[i] = rng_f(r);
+}
+__global__ void kat_math(int n, const double* x, double* l, double* e, double* s, double* c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  l[i] = pm_log(x[i]);
+  e[i] = pm_exp(x[i]);
+  double sn, cs;
+  pm_sincos(x[i], sn, cs);
+  s[i] = sn;
+  c[i] = cs;
+}
+}  // namespace
+
+hipError_t launch_kat_rng_fast(int seed, int hist, int n, float* out_dev, hipStream_t stream);
+
+hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream) {
+  if (mode == 1) {
+    hipLaunchKernelGGL(kat_ranecu, dim3(1), dim3(64), 0, stream, seed, batch, hpt, n, out_dev);
+    return hipGetLastError();
+  }
+  return launch_kat_rng_fast(seed, batch, n, out_dev, stream);
+}
+hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream) {
+  hipLaunchKernelGGL(kat_math, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, l, e, s, c);
+  return hipGetLastError();
+}
+}  // namespace mcgpu

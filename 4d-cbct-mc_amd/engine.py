@@ -1,0 +1,239 @@
+"""ctypes binding of the engine's C ABI (`include/mcgpu_amd.h`, built as `libmcgpu_amd.so`).
+
+The product path: there is no CPU fallback -- if the HIP extension is missing, loading fails
+loudly.  PyTorch is used only by callers that want device tensors / `torch.distributed`; this
+module itself needs no torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+MODE_FAST, MODE_COMPAT = 0, 1
+_MODES = {"fast": MODE_FAST, "compat": MODE_COMPAT, MODE_FAST: MODE_FAST, MODE_COMPAT: MODE_COMPAT}
+
+LIB_PATH = Path(__file__).resolve().parent / "libmcgpu_amd.so"
+EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
+
+# every symbol declared in include/mcgpu_amd.h
+ABI_SYMBOLS = (
+    "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
+    "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
+    "mcgpu_launch_projection", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
+    "mcgpu_write_projection", "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
+)
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def load_library(path: Optional[os.PathLike] = None):
+    """dlopen the engine and declare the prototypes.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise ImportError(f"{p} not found: build the HIP engine first (python __graft_entry__.py or make -C 4d-cbct-mc_amd/csrc)")
+    lib = C.CDLL(str(p))
+    missing = [s for s in ABI_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{p} lacks C-ABI symbols: {missing}")
+    vp, cp, ci, cull = C.c_void_p, C.c_char_p, C.c_int, C.c_ulonglong
+    lib.mcgpu_last_error.restype = cp
+    lib.mcgpu_create.argtypes = [cp, ci, C.POINTER(vp)]
+    lib.mcgpu_destroy.argtypes = [vp]
+    lib.mcgpu_destroy.restype = None
+    lib.mcgpu_config_i64.argtypes = [vp, cp, C.POINTER(C.c_longlong)]
+    lib.mcgpu_config_f64.argtypes = [vp, cp, C.POINTER(C.c_double)]
+    lib.mcgpu_host_table.argtypes = [vp, cp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.mcgpu_projection_file_name.argtypes = [vp, ci, cp, C.c_size_t]
+    lib.mcgpu_image_words.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.mcgpu_launch_shape.argtypes = [cull, ci, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(cull)]
+    lib.mcgpu_advance_seed.argtypes = [ci, cull, ci]
+    lib.mcgpu_launch_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, vp]
+    lib.mcgpu_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.mcgpu_clear_image.argtypes = [vp, vp, vp]
+    lib.mcgpu_run_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, C.POINTER(C.c_double), C.POINTER(cull)]
+    lib.mcgpu_write_projection.argtypes = [vp, ci, vp, cull, C.c_double, cp]
+    lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
+    lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+    lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise EngineError(rc, load_library().mcgpu_last_error().decode(errors="replace"))
+
+
+def launch_shape(histories: int, threads_per_block: int, histories_per_thread: int):
+    """(blocks, histories_per_thread, total_histories) of the reference launch (MC-GPU_v1.3.cu:823-841)."""
+    b, h, t = C.c_int(), C.c_int(), C.c_ulonglong()
+    _check(load_library().mcgpu_launch_shape(int(histories), threads_per_block, histories_per_thread, C.byref(b), C.byref(h), C.byref(t)))
+    return b.value, h.value, t.value
+
+
+def advance_seed(batch_number: int, total_histories: int, seed: int) -> int:
+    return load_library().mcgpu_advance_seed(batch_number, int(total_histories), seed)
+
+
+def write_voxel_file(path, n, spacing_cm, material_zyx: np.ndarray, density_zyx: np.ndarray, gzip: bool = True):
+    m = np.ascontiguousarray(material_zyx, dtype=np.uint8)
+    d = np.ascontiguousarray(density_zyx, dtype=np.float32)
+    assert m.size == d.size == int(n[0]) * int(n[1]) * int(n[2])
+    _check(load_library().mcgpu_write_voxel_file(str(path).encode(), (C.c_int * 3)(*map(int, n)), (C.c_float * 3)(*map(float, spacing_cm)),
+                                                 m.ctypes.data, d.ctypes.data, int(bool(gzip))))
+
+
+class Context:
+    """One loaded simulation (input file + tables), optionally resident on one GPU."""
+
+    def __init__(self, input_path, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.mcgpu_create(str(input_path).encode(), int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+        self.input_path = str(input_path)
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mcgpu_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- queries
+    def geti(self, key: str) -> int:
+        v = C.c_longlong()
+        _check(self.lib.mcgpu_config_i64(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def getf(self, key: str) -> float:
+        v = C.c_double()
+        _check(self.lib.mcgpu_config_f64(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def host_table(self, name: str, dtype=np.uint8) -> np.ndarray:
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.mcgpu_host_table(self.h, name.encode(), C.byref(p), C.byref(n)))
+        buf = (C.c_char * n.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    @property
+    def num_projections(self) -> int:
+        return self.geti("num_projections")
+
+    @property
+    def image_words(self) -> int:
+        n = C.c_size_t()
+        _check(self.lib.mcgpu_image_words(self.h, C.byref(n)))
+        return n.value
+
+    @property
+    def detector_shape(self):
+        return self.geti("num_pixels_z"), self.geti("num_pixels_x")
+
+    def projection_file_name(self, p: int) -> str:
+        buf = C.create_string_buffer(1024)
+        _check(self.lib.mcgpu_projection_file_name(self.h, p, buf, 1024))
+        return buf.value.decode()
+
+    # -- running
+    def launch(self, p: int, image_dev_ptr: int, count: int, mode="fast", seed: Optional[int] = None, first: int = 0,
+               hpt: Optional[int] = None, stream: int = 0):
+        """Asynchronous launch adding into a caller-owned device buffer (e.g. a torch int64 tensor's data_ptr())."""
+        seed = self.geti("seed") if seed is None else seed
+        hpt = self.geti("histories_per_thread") if hpt is None else hpt
+        _check(self.lib.mcgpu_launch_projection(self.h, p, _MODES[mode], int(seed), int(first), int(count), int(hpt),
+                                                C.c_void_p(image_dev_ptr), C.c_void_p(stream)))
+
+    def clear(self, image_dev_ptr: int, stream: int = 0):
+        _check(self.lib.mcgpu_clear_image(self.h, C.c_void_p(image_dev_ptr), C.c_void_p(stream)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(self.lib.mcgpu_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def run_projection(self, p: int, count: int, mode="fast", seed: Optional[int] = None, first: int = 0, hpt: Optional[int] = None):
+        """Synchronous: returns (image uint64[4, Nz, Nx], kernel_seconds, histories_done)."""
+        seed = self.geti("seed") if seed is None else seed
+        hpt = self.geti("histories_per_thread") if hpt is None else hpt
+        img = np.zeros(self.image_words, dtype=np.uint64)
+        secs, done = C.c_double(), C.c_ulonglong()
+        _check(self.lib.mcgpu_run_projection(self.h, p, _MODES[mode], int(seed), int(first), int(count), int(hpt), img.ctypes.data,
+                                             C.byref(secs), C.byref(done)))
+        nz, nx = self.detector_shape
+        return img.reshape(4, nz, nx), secs.value, done.value
+
+    def reference_shape(self, histories: Optional[int] = None):
+        """(batches, hpt, total_histories) the reference would launch for `histories` (COMPAT mode units)."""
+        histories = self.geti("total_histories") if histories is None else histories
+        tpb, hpt = self.geti("threads_per_block"), self.geti("histories_per_thread")
+        blocks, hpt, total = launch_shape(histories, tpb, hpt)
+        return blocks * tpb, hpt, total
+
+    def write_projection(self, p: int, image: np.ndarray, total_histories: int, seconds: float = 0.0, file_name: Optional[str] = None):
+        img = np.ascontiguousarray(image, dtype=np.uint64).reshape(-1)
+        assert img.size == self.image_words
+        _check(self.lib.mcgpu_write_projection(self.h, p, img.ctypes.data, int(total_histories), float(seconds),
+                                               file_name.encode() if file_name else None))
+        return file_name or self.projection_file_name(p)
+
+    def run_all(self, mode="fast", write_projections=True, histories: Optional[int] = None):
+        """The projection loop of main() (MC-GPU_v1.3.cu:667-1056) on this context's GPU."""
+        out = []
+        seed = self.geti("seed")
+        histories = self.geti("total_histories") if histories is None else histories
+        for p in range(self.num_projections):
+            if _MODES[mode] == MODE_COMPAT:
+                batches, hpt, total = self.reference_shape(histories)
+                img, secs, done = self.run_projection(p, batches, mode, seed=seed, hpt=hpt)
+                seed = advance_seed(1, total, seed)
+            else:
+                img, secs, done = self.run_projection(p, histories, mode, seed=seed)
+            name = self.write_projection(p, img, done, secs) if write_projections else None
+            out.append((name, img, secs, done))
+        return out
+
+    # -- known-answer hooks
+    def kat_rng(self, mode, seed: int, batch: int, hpt: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.float32)
+        _check(self.lib.mcgpu_kat_rng(self.h, _MODES[mode], seed, batch, hpt, n, out.ctypes.data))
+        return out
+
+    def kat_math(self, x: Sequence[float]):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        outs = [np.zeros_like(x) for _ in range(4)]
+        _check(self.lib.mcgpu_kat_math(self.h, x.size, x.ctypes.data, *[o.ctypes.data for o in outs]))
+        return outs
+
+
+def create(input_path, device: int = 0) -> Context:
+    return Context(input_path, device)

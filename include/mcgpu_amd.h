@@ -1,0 +1,115 @@
+/*
+ * mcgpu_amd.h -- C ABI of the MI355X-native Monte Carlo CBCT projection engine.
+ *
+ * The reference (IPMI-ICNS-UKE/4d-cbct-mc) exposes NO in-process interface for this path: its
+ * boundary is process + files (`mpirun -n <ngpu> MC-GPU_v1.3.x input.in`, cbctmc/mc/simulation.py:187-198;
+ * SURVEY.md 8b).  This header factors that executable's main() (docker/mcgpu/MC-GPU_v1.3.cu:377-1214)
+ * into entry points with plain pointers and sizes, so the same engine can be driven by
+ *   - the drop-in executable `MC-GPU_v1.3.x` (4d-cbct-mc_amd/csrc/main.cpp),
+ *   - the Python mirror of cbctmc.mc (ctypes, 4d-cbct-mc_amd/engine.py),
+ *   - tests and bench.py.
+ * Each entry point cites the reference code it replaces.  All functions return 0 on success or a
+ * negative error code (the reference's exit codes: -1 input/GPU, -2 parse/alloc, -3 output);
+ * mcgpu_last_error() gives the message (it always contains "ERROR", which is what
+ * cbctmc/mc/simulation.py:204 greps the engine log for).  No exceptions cross the ABI.
+ * Ownership: the context owns host tables and device tables; callers own image buffers.
+ */
+#ifndef MCGPU_AMD_H_
+#define MCGPU_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcgpu_ctx mcgpu_ctx;
+
+/* Kernel personalities.
+ * FAST   : production path -- counter-based per-history RNG streams (Philox4x32-10 seeding a
+ *          xoshiro128++ lane generator), gfx950 native transcendental instructions, exactly
+ *          n_histories histories; statistically equivalent to the reference (3-sigma per pixel).
+ * COMPAT : RANECU leap-frog streams (batch <-> thread mapping of MC-GPU_kernel_v1.3.cu:198,841-894),
+ *          the reference CPU-build arithmetic and the portable math of oracle/mcgpu_oracle.c;
+ *          integer tallies are bit-identical to the CPU oracle. */
+#define MCGPU_MODE_FAST 0
+#define MCGPU_MODE_COMPAT 1
+
+int mcgpu_abi_version(void);
+const char *mcgpu_last_error(void);
+
+/* read_input + init_energy_spectrum + set_CT_trajectory + load_voxels + load_material
+ * (MC-GPU_v1.3.cu:490-562) and, when device_id >= 0, init_CUDA_device (:2454-2724): select the
+ * device and upload all tables.  device_id < 0 builds the host model only (no HIP call is made). */
+int mcgpu_create(const char *input_path, int device_id, mcgpu_ctx **out);
+void mcgpu_destroy(mcgpu_ctx *ctx);
+
+/* Scalars parsed from the input file (MC-GPU_v1.3.cu:1280-1615).  Keys: "total_histories", "seed",
+ * "gpu_id", "threads_per_block", "histories_per_thread", "num_projections", "enable_specific_angles",
+ * "num_voxels_x|y|z", "num_pixels_x|z", "num_materials_used", "num_energy_values", "palette_size",
+ * "volume_bytes_device". */
+int mcgpu_config_i64(const mcgpu_ctx *ctx, const char *key, long long *value);
+/* Keys: "D_angle", "initial_angle", "angularROI_0", "angularROI_1", "SRotAxisD", "vertical_translation",
+ * "mean_energy_spectrum", "e0", "ide". */
+int mcgpu_config_f64(const mcgpu_ctx *ctx, const char *key, double *value);
+
+/* Host tables in the reference's own layouts (MC-GPU_v1.3.h:155-264), for cross-checks against the
+ * reference/oracle: "source_data" (80 B x nproj), "detector_data" (100 B x nproj), "voxel_mat_dens"
+ * (float2 x nvox, built on demand), "mfp_woodcock", "mfp_a", "mfp_b", "xco","pco","aco","bco","pmax",
+ * "itlco","ituco","fco","uico","fj0","noscco","espc","espc_cutoff","espc_alias","density_max",
+ * "density_nominal","voxel_size","inv_voxel_size","size_bbox".  The pointer stays valid until destroy. */
+int mcgpu_host_table(mcgpu_ctx *ctx, const char *name, const void **data, size_t *bytes);
+
+/* Output file name of projection p: "<base>_%010.6fdeg" with the float32 angle (MC-GPU_v1.3.cu:2787-2803). */
+int mcgpu_projection_file_name(const mcgpu_ctx *ctx, int p, char *buf, size_t buf_bytes);
+
+/* Number of uint64 tally words per projection: 4 * Nx * Nz (MC-GPU_v1.3.cu:1848-1849). */
+int mcgpu_image_words(const mcgpu_ctx *ctx, size_t *words);
+
+/* Launch sizing of the reference (MC-GPU_v1.3.cu:823-841): blocks of `threads` threads, `hpt`
+ * histories per thread (raised when blocks would exceed 65535); total = blocks*threads*hpt. */
+int mcgpu_launch_shape(unsigned long long histories, int threads_per_block, int histories_per_thread, int *blocks,
+                       int *hpt_out, unsigned long long *total_histories);
+
+/* update_seed_PRNG (MC-GPU_v1.3.cu:3456-3485): seed for the next projection. */
+int mcgpu_advance_seed(int batch_number, unsigned long long total_histories, int seed);
+
+/* track_particles<<<>>> for projection p (MC-GPU_v1.3.cu:861; kernel MC-GPU_kernel_v1.3.cu:120-384),
+ * asynchronous on `hip_stream` (a hipStream_t, NULL = default stream), ADDING into the caller's device
+ * buffer image_dev[4*Nx*Nz] (uint64).  History sharding: the launch simulates
+ *   FAST  : history ids [first, first+count)            (count = n_histories for a single GPU)
+ *   COMPAT: batches     [first, first+count) of `hpt` histories each (batch b uses RANECU stream b)
+ * so ranks given disjoint ranges produce images whose sum equals the single-GPU image exactly.
+ * `seed` is the RNG seed for this projection; `hpt` is ignored in FAST mode. */
+int mcgpu_launch_projection(mcgpu_ctx *ctx, int p, int mode, int seed, unsigned long long first, unsigned long long count,
+                            int hpt, void *image_dev, void *hip_stream);
+/* Milliseconds between the HIP events recorded around the most recent launch on its stream
+ * (synchronises on the stop event). */
+int mcgpu_last_kernel_ms(mcgpu_ctx *ctx, float *ms);
+/* hipMemsetAsync of an image buffer (init_image_array_GPU, MC-GPU_kernel_v1.3.cu:56-72). */
+int mcgpu_clear_image(mcgpu_ctx *ctx, void *image_dev, void *hip_stream);
+
+/* Convenience, synchronous: allocate+zero a device image, launch, wait, copy to image_host[4*Nx*Nz]
+ * (MC-GPU_v1.3.cu:861-907).  kernel_seconds / histories_done may be NULL. */
+int mcgpu_run_projection(mcgpu_ctx *ctx, int p, int mode, int seed, unsigned long long first, unsigned long long count, int hpt,
+                         uint64_t *image_host, double *kernel_seconds, unsigned long long *histories_done);
+
+/* report_image (MC-GPU_v1.3.cu:2783-2953): write the ASCII projection file (file_name NULL = the
+ * reference's name for projection p).  Values = image * (1/100) * inv_px_X * inv_px_Z / total_histories. */
+int mcgpu_write_projection(mcgpu_ctx *ctx, int p, const uint64_t *image_host, unsigned long long total_histories, double seconds,
+                           const char *file_name);
+
+/* Voxel geometry writer (cbctmc/mc/voxel_data.pyx:12-72 + mcgpu_geometry.jinja2 header fields):
+ * material/density are [z][y][x] contiguous, spacing in cm. */
+int mcgpu_write_voxel_file(const char *path, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density,
+                           int gzip);
+
+/* Device-side known-answer hooks used by the parity tests (each runs a tiny kernel on the context's device). */
+int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n, float *out_f32);
+int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, double *out_exp, double *out_sin, double *out_cos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCGPU_AMD_H_ */

@@ -1,0 +1,38 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def case_dir(tmp_path_factory):
+    """Builds the small test cases (geometry + .in files) once per session."""
+    import cases
+    base = tmp_path_factory.mktemp("mcgpu_cases")
+    built = {}
+
+    def get(name, **overrides):
+        key = (name, tuple(sorted(overrides.items())))
+        if key not in built:
+            sub = base / (name + ("_" + str(len(built)) if overrides else ""))
+            built[key] = cases.build_case(name, sub, **overrides)
+        return built[key]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def engine():
+    import cases
+    eng = cases.pkg.engine
+    eng.load_library()
+    return eng

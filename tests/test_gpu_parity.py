@@ -1,0 +1,115 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP kernels, through the C ABI, against the CPU oracle.
+
+COMPAT personality: integer tallies must be BIT-IDENTICAL to oracle/mcgpu_oracle.c (portable math).
+FAST personality  : per-pixel agreement within 3 sigma of the (compound-)Poisson noise, the tolerance
+                    BASELINE.json's north_star states.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity
+
+pytestmark = pytest.mark.gpu
+
+CASE_BATCHES = [("air", 256), ("water", 512), ("catphan64", 512), ("catphan64_ct", 256), ("slab_angles", 256)]
+
+
+@pytest.fixture(scope="module")
+def gpu_engine(engine):
+    return engine
+
+
+def test_portable_math_bit_exact(gpu_engine, case_dir):
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(1e-9, 1.0, 4000), rng.uniform(1.0, 8.0, 2000), rng.uniform(-40.0, 0.5, 2000),
+                        np.float32(rng.uniform(0, 1, 2000)).astype(np.float64) * 6.283185307179586])
+    with gpu_engine.create(case_dir("air"), device=0) as ctx:
+        lg, ex, sn, cs = ctx.kat_math(np.abs(x) + 1e-300)
+        lib = ol.oracle()
+        import ctypes as C
+        for i, v in enumerate(np.abs(x) + 1e-300):
+            s, c = C.c_double(), C.c_double()
+            lib.oracle_pm_sincos(v, C.byref(s), C.byref(c))
+            assert lg[i] == lib.oracle_pm_log(v)
+            assert ex[i] == lib.oracle_pm_exp(v) or (np.isinf(ex[i]) and np.isinf(lib.oracle_pm_exp(v)))
+            assert sn[i] == s.value and cs[i] == c.value
+
+
+def test_ranecu_stream_bit_exact(gpu_engine, case_dir):
+    import ctypes as C
+    with gpu_engine.create(case_dir("air"), device=0) as ctx:
+        for batch, hpt, seed in [(0, 150, 42), (1, 150, 42), (66666, 1431, 1267439713), (123456, 7, 99)]:
+            got = ctx.kat_rng("compat", seed, batch, hpt, 2000)
+            s = (C.c_int * 2)()
+            ol.oracle().oracle_init_prng(batch, hpt, seed, s)
+            want = np.array([ol.oracle().oracle_ranecu(s) for _ in range(2000)], dtype=np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,nbatch", CASE_BATCHES)
+def test_compat_kernel_bit_exact_vs_oracle(gpu_engine, case_dir, name, nbatch):
+    with gpu_engine.create(case_dir(name), device=0) as ctx:
+        T = parity.tables_from_context(ctx)
+        for p in range(ctx.num_projections):
+            seed = 42 + 1000 * p
+            img_gpu, secs, done = ctx.run_projection(p, nbatch, mode="compat", seed=seed, hpt=150)
+            img_cpu, _ = T.track(p, seed, 0, nbatch, 150, ol.MATH_PORTABLE, n_threads=4)
+            assert done == nbatch * 150
+            assert img_gpu.sum() > 0
+            diff = np.count_nonzero(img_gpu.reshape(-1) != img_cpu)
+            assert diff == 0, f"{name} projection {p}: {diff} tally words differ"
+
+
+def test_compat_history_sharding_is_exact(gpu_engine, case_dir):
+    """Two ranks given disjoint batch ranges sum to the single-GPU image (what the multi-GPU reduce relies on)."""
+    with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
+        whole, _, _ = ctx.run_projection(0, 300, mode="compat", seed=42, hpt=100)
+        a, _, _ = ctx.run_projection(0, 130, mode="compat", seed=42, hpt=100, first=0)
+        b, _, _ = ctx.run_projection(0, 170, mode="compat", seed=42, hpt=100, first=130)
+        assert np.array_equal(whole, a + b)
+
+
+def test_fast_history_sharding_and_determinism(gpu_engine, case_dir):
+    with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
+        n = 400_000
+        whole, _, done = ctx.run_projection(0, n, mode="fast", seed=7)
+        again, _, _ = ctx.run_projection(0, n, mode="fast", seed=7)
+        assert done == n
+        assert np.array_equal(whole, again), "integer tallies must not depend on scheduling"
+        a, _, _ = ctx.run_projection(0, 150_000, mode="fast", seed=7, first=0)
+        b, _, _ = ctx.run_projection(0, 250_000, mode="fast", seed=7, first=150_000)
+        assert np.array_equal(whole, a + b)
+        other, _, _ = ctx.run_projection(0, n, mode="fast", seed=8)
+        assert not np.array_equal(whole, other)
+
+
+@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles"])
+def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
+    """FAST vs oracle (LIBM math = the reference's own arithmetic): every class image, per pixel."""
+    with gpu_engine.create(case_dir(name), device=0) as ctx:
+        T = parity.tables_from_context(ctx)
+        p = ctx.num_projections - 1
+        nb, hpt = 4000, 150  # 6e5 oracle histories
+        img_cpu, _ = T.track(p, 42, 0, nb, hpt, ol.MATH_LIBM, n_threads=8)
+        n_cpu = nb * hpt
+        n_gpu = 20_000_000
+        img_gpu, secs, done = ctx.run_projection(p, n_gpu, mode="fast", seed=42)
+        img_cpu = img_cpu.reshape(img_gpu.shape)
+        # integral quantities: detected energy per history, per image class
+        for k in range(4):
+            a, b = img_gpu[k].sum() / done, img_cpu[k].sum() / n_cpu
+            counts = img_cpu[k].sum() / 6.0e6
+            if counts > 200:
+                rel = 3.5 * np.sqrt(1.6 / counts)  # 3.5 sigma on the oracle's (much smaller) sample
+                assert abs(a / b - 1.0) < rel + 2e-3, f"{name} class {k}: energy/history {a:.6g} vs {b:.6g}"
+        # per pixel, coarse-grained 3x3 so that oracle pixels hold enough counts
+        nz, nx = img_gpu.shape[1:]
+        g = img_gpu[:, : nz // 3 * 3, : nx // 3 * 3].reshape(4, nz // 3, 3, nx // 3, 3).sum(axis=(2, 4))
+        c = img_cpu[:, : nz // 3 * 3, : nx // 3 * 3].reshape(4, nz // 3, 3, nx // 3, 3).sum(axis=(2, 4))
+        z, mask = parity.poisson_z(g, done, c, n_cpu)
+        assert mask.sum() > 50
+        frac3 = np.mean(np.abs(z[mask]) > 3.0)
+        assert frac3 < 0.01, f"{name}: {frac3:.4f} of {mask.sum()} pixels beyond 3 sigma (expect ~0.003)"
+        assert np.abs(z[mask]).max() < 6.0
+        assert abs(z[mask].mean()) < 0.25
