@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- photon histories/s of the MC CBCT projection hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): Catphan604 phantom in a 512^3 volume @ 1 mm, Varian half-fan geometry,
+1848x768 detector, 894-projection trajectory, 1e8 histories per projection per GPU, default spectrum,
+real PENELOPE material tables.  A "step" is one projection: the photon-history kernel over one batch of
+histories (FAST personality), plus -- for N > 1 -- the RCCL sum-reduce of the 45 MB detector tally to
+rank 0.  Inputs (volume, tables) are resident in HBM before the timed region.  Weak scaling: every rank
+simulates `--histories` histories of each projection with its own disjoint history-id range.
+
+Prints ONE JSON line on rank 0 (driver contract) carrying `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+# Algorithmic bytes per history, Catphan604, reference table layout:
+# 8 B x 21.26 voxel gathers + 24 B x 1.84 MFP rows + 8 B x 1.47 Woodcock rows + 16 B x 0.93 tally RMW.
+ALGO_BYTES_PER_HISTORY = 241.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_workload(workdir: Path, n_vox: int, histories: int, n_proj: int, engine):
+    """Catphan604 geometry + input file in the reference's wire formats (written once, by rank 0)."""
+    import cases
+    pkg = cases.pkg
+    geo = pkg.geometry.MCCatPhan604Geometry(shape=(n_vox,) * 3, image_spacing=(1.0, 1.0, 1.0))
+    mats = cases.material_files()
+    sim = pkg.simulation.MCSimulation(geo, mats, cases.spectrum_file(), n_histories=histories, n_projections=n_proj,
+                                      angle_between_projections=360.0 / n_proj)
+    return sim.prepare_simulation(workdir, compress_geometry=False, engine=engine)
+
+
+def cpu_baseline(ctx, seconds_budget: float = 12.0):
+    """The restated CPU oracle (oracle/mcgpu_oracle.c, LIBM math == reference arithmetic) on a bounded
+    sample of the same workload, on this host's cores.  Reported, never the target."""
+    import oracle_lib as ol
+    import parity
+    T = parity.tables_from_context(ctx)
+    cores = os.cpu_count() or 1
+    hpt = 150
+    # calibrate on a small single-thread sample, then size the all-core sample to the time budget
+    t0 = time.perf_counter()
+    cnt = ol.OracleCounters()
+    T.track(0, 42, 0, 200, hpt, ol.MATH_LIBM, n_threads=1, counters=cnt)
+    t1 = time.perf_counter() - t0
+    rate1 = 200 * hpt / t1
+    nb = int(max(cores * 64, min(rate1 * cores * seconds_budget / hpt, 4_000_000)))
+    t0 = time.perf_counter()
+    T.track(0, 42, 200, nb, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
+    t2 = time.perf_counter() - t0
+    c = cnt.as_dict()
+    h = float(c["histories"])
+    per_hist = {k: round(c[k] / h, 4) for k in ("steps", "voxel_reads", "mfp_reads", "woodcock_reads", "compton", "rayleigh", "photo", "rng", "tally_calls", "tally_hits")}
+    return {
+        "value": nb * hpt / t2, "unit": "histories/s", "cores": cores, "kind": "port",
+        "sample": f"{nb * hpt} histories of projection 0 of the same workload, OpenMP over RANECU batches (oracle/mcgpu_oracle.c, libm math)",
+        "per_core_value": rate1, "events_per_history": per_hist,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--histories", type=float, default=1e8, help="histories per projection per GPU")
+    ap.add_argument("--voxels", type=int, default=512)
+    ap.add_argument("--projections", type=int, default=894)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=None)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import cases
+    eng = cases.pkg.engine
+    eng.load_library()
+
+    H = int(args.histories)
+    workdir = Path(args.workdir or os.path.join(tempfile.gettempdir(), f"mcgpu_bench_{args.voxels}_{args.projections}"))
+    inp = workdir / "input.in"
+    t_prep0 = time.perf_counter()
+    if rank == 0 and not (inp.exists() and (workdir / "geometry.vox").exists()):
+        workdir.mkdir(parents=True, exist_ok=True)
+        build_workload(workdir, args.voxels, H, args.projections, eng)
+    if dist:
+        dist.barrier()
+    t_prep = time.perf_counter() - t_prep0
+    t_load0 = time.perf_counter()
+    ctx = eng.create(inp, device=local_rank)
+    t_load = time.perf_counter() - t_load0
+
+    nz, nx = ctx.detector_shape
+    image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    nproj = ctx.num_projections
+    seed = ctx.geti("seed")
+    kernel_ms = []
+
+    def step(i, timed):
+        p = (i * 149) % nproj  # spread the sampled projections over the arc
+        ctx.clear(image.data_ptr(), stream)
+        # disjoint history ids per rank: [rank*H, (rank+1)*H)
+        ctx.launch(p, image.data_ptr(), H, mode="fast", seed=seed, first=rank * H, stream=stream)
+        if timed:
+            kernel_ms.append(ctx.last_kernel_ms())
+        if dist:
+            dist.reduce(image, dst=0, op=dist.ReduceOp.SUM)  # per-projection detector tally -> rank 0 (RCCL over xGMI)
+
+    for i in range(args.warmup):
+        step(i, False)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    detected = int(image.sum().item()) if rank == 0 else 0
+
+    if rank == 0:
+        total_hist = float(H) * world * args.steps
+        value = total_hist / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        achieved = ALGO_BYTES_PER_HISTORY * H / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "photon histories/sec (512^3 vol, 894 proj)", "value": value, "unit": "histories/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"catphan604_{args.voxels}cube_1mm_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
+                       "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
+                       "parallelism": f"history-sharded x{world}, RCCL sum-reduce of the detector tally per projection",
+                       "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
+                       "volume_bytes": ctx.geti("volume_bytes_device"), "per_gpu_value": value / world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "track_kernel<u8> (fast)", "kernel_ms_avg": k_ms,
+                         "algorithmic_bytes_per_history": ALGO_BYTES_PER_HISTORY},
+            "timing": {"prepare_inputs_s": t_prep, "load_and_upload_s": t_load},
+            "check": {"detected_energy_units_last_projection": detected},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
