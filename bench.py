@@ -51,15 +51,18 @@ def cpu_baseline(ctx, seconds_budget: float = 12.0):
     T = parity.tables_from_context(ctx)
     cores = os.cpu_count() or 1
     hpt = 150
-    # calibrate on a small single-thread sample, then size the all-core sample to the time budget
+    # calibrate: single-thread sample, then a short all-core sample, then the timed all-core sample
     t0 = time.perf_counter()
     cnt = ol.OracleCounters()
     T.track(0, 42, 0, 200, hpt, ol.MATH_LIBM, n_threads=1, counters=cnt)
-    t1 = time.perf_counter() - t0
-    rate1 = 200 * hpt / t1
-    nb = int(max(cores * 64, min(rate1 * cores * seconds_budget / hpt, 4_000_000)))
+    rate1 = 200 * hpt / (time.perf_counter() - t0)
+    nb_cal = cores * 8
     t0 = time.perf_counter()
-    T.track(0, 42, 200, nb, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
+    T.track(0, 42, 200, nb_cal, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
+    rate_all = nb_cal * hpt / (time.perf_counter() - t0)
+    nb = int(max(cores * 16, rate_all * seconds_budget / hpt))
+    t0 = time.perf_counter()
+    T.track(0, 42, 200 + nb_cal, nb, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
     t2 = time.perf_counter() - t0
     c = cnt.as_dict()
     h = float(c["histories"])

@@ -451,8 +451,14 @@ void oracle_source(const oracle_tables *T, int num_p, int *seed2, float *pos3, f
 /* ------------------------------------------------------------------------------------------
  * tally_image (K.cu:482-604), CPU branches (:553-565 rotated detector, :589-600 detector at +Y)
  * ------------------------------------------------------------------------------------------ */
+static inline void tally_add(uint64_t *word, unsigned long long v, int shared)
+{
+  if (shared) __atomic_fetch_add(word, (uint64_t)v, __ATOMIC_RELAXED);  /* OpenMP runs: integer sum, order-independent */
+  else *word += (uint64_t)v;
+}
+
 static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state, uint64_t *image, const src_t *S, const det_t *D,
-                        oracle_counters *C)
+                        oracle_counters *C, int shared)
 {
   float dist, rot;
   C->tally_calls++;
@@ -469,7 +475,7 @@ static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state,
       rot = D->rot_inv[6] * pos->x + D->rot_inv[7] * pos->y + D->rot_inv[8] * pos->z;
       float pz = floor((rot - D->corner_min_rotated_to_Y.z) * D->inv_pixel_size_Z);
       if ((pz > -0.1f) && (pz < (D->num_pixels_y - 0.1f))) {
-        image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)] += (unsigned long long)(energy * 100.0f + 0.5f);
+        tally_add(&image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)], (unsigned long long)(energy * 100.0f + 0.5f), shared);
         C->tally_hits++;
       }
     }
@@ -480,7 +486,7 @@ static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state,
     if ((px > -0.1f) && (px < (D->num_pixels_x - 0.1f))) {
       float pz = floor((pos->z + dist * dir->z - D->corner_min_rotated_to_Y.z) * D->inv_pixel_size_Z);
       if ((pz > -0.1f) && (pz < (D->num_pixels_y - 0.1f))) {
-        image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)] += (unsigned long long)(energy * 100.0f + 0.5f);
+        tally_add(&image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)], (unsigned long long)(energy * 100.0f + 0.5f), shared);
         C->tally_hits++;
       }
     }
@@ -490,7 +496,7 @@ static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state,
 /* ------------------------------------------------------------------------------------------
  * track_particles (K.cu:120-384): one batch of `hpt` histories
  * ------------------------------------------------------------------------------------------ */
-static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, int seed_input, uint64_t *image, int pm, oracle_counters *C)
+static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, int seed_input, uint64_t *image, int pm, oracle_counters *C, int shared)
 {
   const src_t *S = (const src_t *)T->source_data + num_p;
   const det_t *D = (const det_t *)T->detector_data + num_p;
@@ -563,7 +569,7 @@ static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, i
       }
       if (index < 0) break;
     }
-    if (index > -1) tally_image(energy, &pos, &dir, scatter_state, image, S, D, C);
+    if (index > -1) tally_image(energy, &pos, &dir, scatter_state, image, S, D, C, shared);
   }
 }
 
@@ -577,34 +583,26 @@ static void add_counters(oracle_counters *a, const oracle_counters *b)
 int oracle_track(const oracle_tables *T, int num_p, int seed_input, int batch0, int nbatches, int hpt, uint64_t *image, int math_mode,
                  int n_threads, oracle_counters *counters)
 {
-  const det_t *D = (const det_t *)T->detector_data + num_p;
-  const size_t nimg = (size_t)4 * D->total_num_pixels;
   oracle_counters total;
   memset(&total, 0, sizeof total);
   if (n_threads <= 1) {
     int b;
-    for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &total);
+    for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &total, 0);
   } else {
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
     {
-      uint64_t *priv = (uint64_t *)calloc(nimg, sizeof(uint64_t));
       oracle_counters c;
       int b;
-      size_t k;
       memset(&c, 0, sizeof c);
-#pragma omp for schedule(dynamic, 16)
-      for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, priv, math_mode, &c);
+#pragma omp for schedule(dynamic, 4)
+      for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &c, 1);
 #pragma omp critical
-      {
-        for (k = 0; k < nimg; k++) image[k] += priv[k];
-        add_counters(&total, &c);
-      }
-      free(priv);
+      add_counters(&total, &c);
     }
 #else
     int b;
-    for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &total);
+    for (b = batch0; b < batch0 + nbatches; b++) track_batch(T, b, hpt, num_p, seed_input, image, math_mode, &total, 0);
 #endif
   }
   if (counters) add_counters(counters, &total);

@@ -1,0 +1,104 @@
+"""CPU tests: the product's host model (C++ parsers/table builders behind the C ABI, device_id = -1)
+against golden vectors dumped from the reference's read_input / load_voxels / load_material /
+set_CT_trajectory / init_energy_spectrum / report_image (oracle/gen_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util as gu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_tables_bit_identical_to_reference(name, case_dir, engine):
+    g = gu.load(f"case_{name}.npz")
+    with engine.create(case_dir(name), device=-1) as ctx:
+        sc = gu.scalars(g)
+        nproj = int(sc["num_projections"])
+        assert ctx.num_projections == nproj
+        for k in ("total_histories", "seed", "gpu_id", "threads_per_block", "histories_per_thread", "enable_specific_angles"):
+            assert ctx.geti(k) == int(sc[k]), k
+        assert np.float32(ctx.getf("mean_energy_spectrum")) == np.float32(sc["mean_energy_spectrum"])
+        if nproj > 1:
+            for k in ("D_angle", "initial_angle", "angularROI_0", "angularROI_1", "SRotAxisD", "vertical_translation"):
+                assert ctx.getf(k) == sc[k], k
+        # per-projection source / detector structs: byte for byte (80 B / 100 B each)
+        assert np.array_equal(ctx.host_table("source_data"), g["source_data"])
+        assert np.array_equal(ctx.host_table("detector_data"), g["detector_data"])
+        # spectrum + Walker alias tables
+        nb = int(g["num_bins_espc"])
+        assert ctx.geti("num_spectrum_bins") == nb
+        assert np.array_equal(ctx.host_table("espc", "<f4")[: nb + 1].view(np.uint32), g["espc"].view(np.uint32))
+        assert np.array_equal(ctx.host_table("espc_cutoff", "<f4")[:nb].view(np.uint32), g["espc_cutoff"].view(np.uint32))
+        assert np.array_equal(ctx.host_table("espc_alias", "<i2")[:nb], g["espc_alias"])
+        # voxel header
+        assert [ctx.geti(f"num_voxels_{a}") for a in "xyz"] == list(g["num_voxels"])
+        assert np.array_equal(ctx.host_table("inv_voxel_size", "<f4"), g["inv_voxel_size"])
+        assert np.array_equal(ctx.host_table("size_bbox", "<f4"), g["size_bbox"])
+        dm, dm_ref = ctx.host_table("density_max", "<f4"), g["density_max"].copy()
+        if dm[0] < 0:  # material 1 absent from the voxels: the reference overwrites its slot with 0.01*nominal (MC-GPU_v1.3.cu:2229-2230)
+            assert dm_ref[0] == np.float32(0.01) * g["density_nominal"][0]
+            dm_ref[0] = dm[0]
+        assert np.array_equal(dm, dm_ref)
+        used = g["used_materials"]
+        assert np.array_equal(np.flatnonzero(ctx.host_table("noscco", "<i4")), used)
+        assert np.array_equal(ctx.host_table("noscco", "<i4"), g["noscco"])
+        assert np.array_equal(ctx.host_table("density_nominal", "<f4")[used], g["density_nominal"][used])
+        assert (np.float32(ctx.getf("e0")), np.float32(ctx.getf("ide"))) == tuple(g["e0_ide"])
+        nv = int(g["num_values"])
+        assert ctx.geti("num_energy_values") == nv
+        A = ctx.host_table("mfp_a", "<f4").reshape(nv, 25, 3)[:, used]
+        B = ctx.host_table("mfp_b", "<f4").reshape(nv, 25, 3)[:, used]
+        W = ctx.host_table("mfp_woodcock", "<f4").reshape(nv, 2)
+        rows = g["sample_rows"]
+        assert np.array_equal(A[rows].view(np.uint32), g["mfp_a_rows"].view(np.uint32))
+        assert np.array_equal(B[rows].view(np.uint32), g["mfp_b_rows"].view(np.uint32))
+        assert np.array_equal(W[rows[rows < nv - 1]].view(np.uint32), g["woodcock_rows"].view(np.uint32))
+        # the reference leaves the last Woodcock entry uninitialised; ours repeats the previous slope
+        assert W[nv - 1, 1] == W[nv - 2, 1] and np.isfinite(W[nv - 1]).all()
+        mine = {
+            "voxel_mat_dens": sha(ctx.host_table("voxel_mat_dens", "<f4")), "mfp_a_used": sha(A), "mfp_b_used": sha(B),
+            "woodcock_but_last": sha(W[: nv - 1]),
+            "pmax_used": sha(ctx.host_table("pmax", "<f4").reshape(-1, 25)[:nv, used]),
+            "rayleigh_used": sha(np.stack([ctx.host_table(k, "<f4").reshape(25, 128)[used] for k in ("xco", "pco", "aco", "bco")])),
+            "itl_itu_used": sha(np.stack([ctx.host_table(k).reshape(25, 128)[used] for k in ("itlco", "ituco")])),
+            "compton_used": sha(np.stack([ctx.host_table(k, "<f4").reshape(40, 25)[:, used] for k in ("fco", "uico", "fj0")])),
+        }
+        for k, v in zip(g["digest_names"], g["digest_values"]):
+            assert mine[str(k)] == str(v), f"table {k} differs from the reference"
+        # output file names (float32 angle, MC-GPU_v1.3.cu:2787-2803)
+        names = [os.path.basename(ctx.projection_file_name(p)) for p in range(nproj)]
+        assert names == [str(s) for s in g["file_names"]]
+        assert all(cases.simulation.PROJECTION_FILE_PATTERN.match(n) for n in names)
+
+
+@pytest.mark.parametrize("name", ["catphan64_ct", "air"])
+def test_ascii_projection_writer_matches_report_image(name, case_dir, engine, tmp_path):
+    """Data lines byte-identical to the reference's fprintf("%.8lf ..."); same line count; np.loadtxt-able."""
+    g = gu.load(f"case_{name}.npz")
+    nb, hpt = [int(v) for v in g["nbatch_hpt"]]
+    with engine.create(case_dir(name), device=-1) as ctx:
+        p = ctx.num_projections - 1
+        img = gu.dense(g, "ref", p, ctx.image_words)
+        out = tmp_path / "proj"
+        ctx.write_projection(p, img, nb * hpt, 1.0, str(out))
+        lines = out.read_text().split("\n")
+        assert len(lines) == int(g["ascii_num_lines"])
+        data = [l for l in lines if not l.startswith("#")]
+        want = [str(s) for s in g["ascii_first_rows"]]
+        assert data[: len(want)] == want
+        comments = [l for l in lines if l.startswith("#")]
+        assert len(comments) == 20 + 5 + 1 - 1 + 0 or len(comments) >= 25
+        assert comments[-3:] == [str(s) for s in g["ascii_comment_tail"]][-3:]  # histories / time / speed footer
+        # the reference consumer (cbctmc/mc/projection.py:42-47)
+        nz, nx = ctx.detector_shape
+        arr = np.loadtxt(out, dtype=np.float64).reshape(nz, nx, 4)
+        norm = (1.0 / 100.0) * float(np.float32(g["detector_data"].view("<f4")[19])) * float(np.float32(g["detector_data"].view("<f4")[20])) / (nb * hpt)
+        back = np.rint(arr / norm).astype(np.uint64)
+        assert np.array_equal(back.transpose(2, 0, 1).reshape(-1), img)
