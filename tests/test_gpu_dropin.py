@@ -13,9 +13,9 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-def _read_like_reference(path, nz, nx):
-    """cbctmc/mc/projection.py:36-51 without the half-fan crop."""
-    data = np.loadtxt(path, dtype=np.float64).astype(np.float32)
+def _read_like_reference(path, nz, nx, dtype=np.float32):
+    """cbctmc/mc/projection.py:36-51 without the half-fan crop (the reference casts to float32)."""
+    data = np.loadtxt(path, dtype=np.float64).astype(dtype)
     return np.flip(data.reshape(nz, nx, 4), axis=0)
 
 
@@ -40,8 +40,8 @@ def test_executable_compat_matches_oracle_and_log_contract(engine, tmp_path):
         for p, name in enumerate(files):
             img, _ = T.track(p, seed, 0, batches, hpt, ol.MATH_PORTABLE, n_threads=4)
             want = np.flip((img.reshape(4, nz, nx).astype(np.float64) * norm).transpose(1, 2, 0), axis=0)
-            got = _read_like_reference(tmp_path / name, nz, nx)
-            assert np.allclose(got, want.astype(np.float32), rtol=0, atol=1.01e-8)
+            got = _read_like_reference(tmp_path / name, nz, nx, np.float64)
+            assert np.allclose(got, want, rtol=0, atol=0.51e-8)  # "%.8lf" text of exactly the oracle's integers
             assert got.sum() > 0
             seed = engine.advance_seed(1, total, seed)  # GPU-build seed stepping between projections (MC-GPU_v1.3.cu:869)
 
