@@ -6,6 +6,9 @@
 //               512^3 Catphan604 -> 128 MiB (fits the 256 MiB Infinity Cache) instead of the
 //               reference's 1 GiB float2 array (MC-GPU_v1.3.cu:2135-2137).
 //   palette   : float2 {density, bits(compact material index)}  (staged in LDS when <=256 entries)
+//   bricks    : u8 per brick of (2^k)^3 voxels, <= 32768 bricks, LDS-resident: the brick's palette index when all
+//               its voxels agree, else 0xFF ("mixed": read the voxel).  Most Woodcock steps land in homogeneous
+//               bricks (air, water body) and never touch the volume.
 //   mfp       : per (energy bin, compact material) one 32-byte record
 //               {a_tot, a_Co, a_Ra, b_tot | b_Co, b_Ra, pmax(bin+1), 0}  -- one aligned 32-B fetch where the
 //               reference reads 2 x float3 from two 7.2 MB tables plus pmax from a third (K.cu:268-269,336).
@@ -20,12 +23,16 @@
 namespace mcgpu {
 
 enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
+constexpr int kTrackBlockThreads = 512;   // 8 waves per workgroup
+constexpr int kMaxBricks = 32768;         // LDS budget of the brick grid (bytes)
 
 struct TrackArgs {
   // geometry
   const void* vol;
   const float* palette;  // float2 pairs {density, bits(mat_c)}
   int vol_kind, palette_size;
+  const unsigned char* bricks;  // brick grid: palette index of a homogeneous brick, 0xFF = mixed (u8 volumes only)
+  int brick_shift, brick_nx, brick_nxy, brick_count;
   int nx, ny, nz, nxy;
   float inv_vs[3];
   float bbox[3];
@@ -52,7 +59,8 @@ struct TrackArgs {
   int seed, hpt;
   unsigned long long first, count;
   unsigned int stream_key;  // FAST: projection index mixed into the Philox key
-  int service_threshold;    // pending lanes per wave that trigger an interaction/tally/source round
+  // parked lanes per wave64 that trigger a batched service of that kind
+  int thresh_compton, thresh_rayleigh, thresh_new;
 };
 
 }  // namespace mcgpu

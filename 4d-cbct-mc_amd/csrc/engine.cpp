@@ -21,6 +21,8 @@ namespace mcgpu {
 
 hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
+int occupancy_track_compat(const TrackArgs& args);
+int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 
@@ -45,6 +47,9 @@ struct DeviceModel {
   size_t vol_bytes = 0;
   int vol_kind = kVolU8, palette_size = 0;
   float* palette = nullptr;
+  unsigned char* bricks = nullptr;
+  int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, bricks_mixed = 0;
+  int resident_fast = 0;  // workgroups per CU (occupancy query), 0 = not asked yet
   float *woodcock = nullptr, *mfp = nullptr;
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
@@ -159,6 +164,34 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     D.vol_bytes = nvox;
     D.palette_size = (int)index_of.size();
     D.palette = D.put(palette);
+    // brick grid: smallest power-of-two brick (>= 4 voxels) that keeps the grid within the LDS budget
+    const int nx = H.voxels.n[0], ny = H.voxels.n[1], nz = H.voxels.n[2];
+    int k = 2;
+    auto nb = [&](int n, int sh) { return (n + (1 << sh) - 1) >> sh; };
+    while ((long)nb(nx, k) * nb(ny, k) * nb(nz, k) > kMaxBricks) ++k;
+    D.brick_shift = k;
+    D.brick_n[0] = nb(nx, k); D.brick_n[1] = nb(ny, k); D.brick_n[2] = nb(nz, k);
+    D.brick_count = D.brick_n[0] * D.brick_n[1] * D.brick_n[2];
+    std::vector<int> first(D.brick_count, -1);
+    std::vector<unsigned char> mixed(D.brick_count, 0);
+    for (int z = 0; z < nz; ++z)
+      for (int y = 0; y < ny; ++y) {
+        const size_t row = ((size_t)z * ny + y) * nx;
+        const size_t brow = ((size_t)(z >> k) * D.brick_n[1] + (y >> k)) * D.brick_n[0];
+        for (int x = 0; x < nx; ++x) {
+          const int b = (int)(brow + (x >> k)), v = idx8[row + x];
+          if (first[b] < 0) first[b] = v;
+          else if (first[b] != v) mixed[b] = 1;
+        }
+      }
+    std::vector<unsigned char> bricks(D.brick_count);
+    D.bricks_mixed = 0;
+    for (int b = 0; b < D.brick_count; ++b) {
+      const bool m = mixed[b] || first[b] < 0 || first[b] >= 0xFF;
+      bricks[b] = m ? 0xFF : (unsigned char)first[b];
+      D.bricks_mixed += m;
+    }
+    D.bricks = D.put(bricks);
   } else {
     D.vol_kind = kVolU16;
     D.vol = D.put(idx16);
@@ -223,6 +256,8 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   TrackArgs A;
   memset(&A, 0, sizeof A);
   A.vol = D.vol; A.palette = D.palette; A.vol_kind = D.vol_kind; A.palette_size = D.palette_size;
+  A.bricks = D.bricks; A.brick_shift = D.brick_shift; A.brick_nx = D.brick_n[0]; A.brick_nxy = D.brick_n[0] * D.brick_n[1];
+  A.brick_count = D.vol_kind == kVolU8 ? D.brick_count : 0;
   A.nx = H.voxels.n[0]; A.ny = H.voxels.n[1]; A.nz = H.voxels.n[2]; A.nxy = A.nx * A.ny;
   for (int k = 0; k < 3; ++k) { A.inv_vs[k] = H.voxels.inv_voxel_size[k]; A.bbox[k] = H.voxels.size_bbox[k]; }
   A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat;
@@ -232,7 +267,11 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.nbins = H.spectrum.num_bins; A.espc = D.espc; A.cutoff = D.cutoff; A.alias = D.alias;
   A.src = H.source[p]; A.det = H.detector[p];
   A.stream_key = (unsigned)p;
-  A.service_threshold = 16;
+  // batching thresholds (lanes of a wave64); tunable for experiments
+  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 24);
+  A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 6);
+  A.thresh_new = env_int("MCGPU_THRESH_NEW", 24);
   return A;
 }
 
@@ -349,6 +388,10 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "volume_kind") *value = ctx->dev.vol_kind;
   else if (k == "volume_bytes_device") *value = (long long)ctx->dev.vol_bytes;
   else if (k == "num_cus") *value = ctx->dev.num_cus;
+  else if (k == "brick_shift") *value = ctx->dev.brick_shift;
+  else if (k == "brick_count") *value = ctx->dev.brick_count;
+  else if (k == "bricks_mixed") *value = ctx->dev.bricks_mixed;
+  else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else return set_error(-2, std::string("unknown integer key: ") + key);
   return 0;
   ABI_END
@@ -437,12 +480,18 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
     if (mode == MCGPU_MODE_COMPAT) {
       require(hpt > 0, -2, "!!ERROR!! mcgpu_launch_projection: histories per thread must be positive in COMPAT mode");
       require(seed > 0 && seed < 2147483399, -2, "!!ERROR!! mcgpu_launch_projection: RANECU seed out of range");
-      const unsigned long long blocks = (count + 255) / 256;
+      const unsigned long long blocks = (count + kTrackBlockThreads - 1) / kTrackBlockThreads;
       require(blocks <= 0x7fffffffULL, -2, "!!ERROR!! mcgpu_launch_projection: too many batches");
       HIP_TRY(launch_track_compat(A, (int)blocks, stream));
     } else {
-      const unsigned long long want = (count + 255) / 256;
-      const unsigned long long resident = (unsigned long long)D.num_cus * 8ULL;
+      // persistent grid: exactly the resident workgroups (an over-subscribed grid would run a second, thin round)
+      if (D.resident_fast <= 0) {
+        const char* v = getenv("MCGPU_BLOCKS_PER_CU");
+        D.resident_fast = v ? atoi(v) : occupancy_track_fast(A);
+        if (D.resident_fast <= 0) D.resident_fast = 1;
+      }
+      const unsigned long long want = (count + kTrackBlockThreads - 1) / kTrackBlockThreads;
+      const unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
       HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
     }
   }
