@@ -61,6 +61,8 @@ struct TrackArgs {
   unsigned int stream_key;  // FAST: projection index mixed into the Philox key
   // parked lanes per wave64 that trigger a batched service of that kind
   int thresh_compton, thresh_rayleigh, thresh_new;
+  unsigned long long* stats;  // diagnostic build only (8 counters), else null
+  unsigned long long* work_counter;  // FAST: next unassigned history offset (zeroed before each launch)
 };
 
 }  // namespace mcgpu

@@ -23,6 +23,7 @@ hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t st
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
 int occupancy_track_compat(const TrackArgs& args);
 int occupancy_track_fast(const TrackArgs& args);
+hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 
@@ -50,6 +51,8 @@ struct DeviceModel {
   unsigned char* bricks = nullptr;
   int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, bricks_mixed = 0;
   int resident_fast = 0;  // workgroups per CU (occupancy query), 0 = not asked yet
+  unsigned long long* stats = nullptr;  // 8 scheduler counters of the diagnostic build
+  unsigned long long* work_counter = nullptr;  // history-id dispenser of the FAST kernel
   float *woodcock = nullptr, *mfp = nullptr;
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
@@ -269,7 +272,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.stream_key = (unsigned)p;
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 24);
+  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 20);
   A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 6);
   A.thresh_new = env_int("MCGPU_THRESH_NEW", 24);
   return A;
@@ -468,7 +471,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
   require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_launch_projection: the context has no device (created with device_id < 0)");
   require(p >= 0 && p < ctx->host.cfg.num_projections, -1, "!!ERROR!! mcgpu_launch_projection: projection index out of range");
   require(image_dev != nullptr, -1, "!!ERROR!! mcgpu_launch_projection: null image buffer");
-  require(mode == MCGPU_MODE_FAST || mode == MCGPU_MODE_COMPAT, -1, "!!ERROR!! mcgpu_launch_projection: unknown mode");
+  require(mode == MCGPU_MODE_FAST || mode == MCGPU_MODE_COMPAT || mode == MCGPU_MODE_FAST_STATS, -1, "!!ERROR!! mcgpu_launch_projection: unknown mode");
   DeviceModel& D = ctx->dev;
   HIP_TRY(hipSetDevice(D.device_id));
   hipStream_t stream = (hipStream_t)hip_stream;
@@ -492,11 +495,32 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       }
       const unsigned long long want = (count + kTrackBlockThreads - 1) / kTrackBlockThreads;
       const unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
-      HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
+      if (!D.work_counter) D.work_counter = D.put(std::vector<unsigned long long>(2, 0ULL));
+      HIP_TRY(hipMemsetAsync(D.work_counter, 0, 8, stream));
+      A.work_counter = D.work_counter;
+      if (mode == MCGPU_MODE_FAST_STATS) {
+        if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(8, 0ULL));
+        A.stats = D.stats;
+        HIP_TRY(launch_track_stats(A, (int)std::min(want, resident), stream));
+      } else {
+        HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
+      }
     }
   }
   HIP_TRY(hipEventRecord(D.ev_stop, stream));
   D.timed = true;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_scheduler_stats(mcgpu_ctx* ctx, unsigned long long* out8, int reset) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && out8, -1, "!!ERROR!! mcgpu_scheduler_stats: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  if (!ctx->dev.stats) { for (int k = 0; k < 8; ++k) out8[k] = 0; return 0; }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out8, ctx->dev.stats, 64, hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(ctx->dev.stats, 0, 64));
   return 0;
   ABI_END
 }

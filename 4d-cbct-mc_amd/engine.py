@@ -13,8 +13,9 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-MODE_FAST, MODE_COMPAT = 0, 1
-_MODES = {"fast": MODE_FAST, "compat": MODE_COMPAT, MODE_FAST: MODE_FAST, MODE_COMPAT: MODE_COMPAT}
+MODE_FAST, MODE_COMPAT, MODE_FAST_STATS = 0, 1, 2
+_MODES = {"fast": MODE_FAST, "compat": MODE_COMPAT, "stats": MODE_FAST_STATS, MODE_FAST: MODE_FAST, MODE_COMPAT: MODE_COMPAT,
+          MODE_FAST_STATS: MODE_FAST_STATS}
 
 LIB_PATH = Path(__file__).resolve().parent / "libmcgpu_amd.so"
 EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
@@ -23,7 +24,7 @@ EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
 ABI_SYMBOLS = (
     "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
-    "mcgpu_launch_projection", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
+    "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
 )
 
@@ -64,6 +65,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_advance_seed.argtypes = [ci, cull, ci]
     lib.mcgpu_launch_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, vp]
     lib.mcgpu_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.mcgpu_scheduler_stats.argtypes = [vp, C.POINTER(cull), ci]
     lib.mcgpu_clear_image.argtypes = [vp, vp, vp]
     lib.mcgpu_run_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, C.POINTER(C.c_double), C.POINTER(cull)]
     lib.mcgpu_write_projection.argtypes = [vp, ci, vp, cull, C.c_double, cp]
@@ -175,6 +177,13 @@ class Context:
 
     def clear(self, image_dev_ptr: int, stream: int = 0):
         _check(self.lib.mcgpu_clear_image(self.h, C.c_void_p(image_dev_ptr), C.c_void_p(stream)))
+
+    def scheduler_stats(self, reset: bool = True) -> dict:
+        """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""
+        out = (C.c_ulonglong * 8)()
+        _check(self.lib.mcgpu_scheduler_stats(self.h, out, int(reset)))
+        names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes")
+        return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

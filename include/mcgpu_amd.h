@@ -35,6 +35,8 @@ typedef struct mcgpu_ctx mcgpu_ctx;
  *          integer tallies are bit-identical to the CPU oracle. */
 #define MCGPU_MODE_FAST 0
 #define MCGPU_MODE_COMPAT 1
+/* FAST with scheduler statistics (diagnostic build of the same kernel; see mcgpu_scheduler_stats). Not for timing. */
+#define MCGPU_MODE_FAST_STATS 2
 
 int mcgpu_abi_version(void);
 const char *mcgpu_last_error(void);
@@ -87,6 +89,9 @@ int mcgpu_launch_projection(mcgpu_ctx *ctx, int p, int mode, int seed, unsigned 
 /* Milliseconds between the HIP events recorded around the most recent launch on its stream
  * (synchronises on the stop event). */
 int mcgpu_last_kernel_ms(mcgpu_ctx *ctx, float *ms);
+/* Scheduler statistics accumulated by MCGPU_MODE_FAST_STATS launches: out8 = {wave loop iterations, sum of flying
+ * lanes, Compton rounds, Compton lanes, Rayleigh rounds, Rayleigh lanes, tally+source rounds, their lanes}. */
+int mcgpu_scheduler_stats(mcgpu_ctx *ctx, unsigned long long *out8, int reset);
 /* hipMemsetAsync of an image buffer (init_image_array_GPU, MC-GPU_kernel_v1.3.cu:56-72). */
 int mcgpu_clear_image(mcgpu_ctx *ctx, void *image_dev, void *hip_stream);
 
