@@ -6,9 +6,10 @@
 //               512^3 Catphan604 -> 128 MiB (fits the 256 MiB Infinity Cache) instead of the
 //               reference's 1 GiB float2 array (MC-GPU_v1.3.cu:2135-2137).
 //   palette   : float2 {density, bits(compact material index)}  (staged in LDS when <=256 entries)
-//   bricks    : u8 per brick of (2^k)^3 voxels, <= 32768 bricks, LDS-resident: the brick's palette index when all
-//               its voxels agree, else 0xFF ("mixed": read the voxel).  Most Woodcock steps land in homogeneous
-//               bricks (air, water body) and never touch the volume.
+//   bricks    : 4 bits per brick of (2^k)^3 voxels, <= 32768 bricks (16 KiB), LDS-resident: code c < 15 when all
+//               voxels of the brick share one palette entry (brick_palette[c], the 15 most frequent such entries),
+//               else 0xF ("mixed": read the voxel).  Most Woodcock steps land in homogeneous bricks (air, water
+//               body) and never touch the volume.
 //   mfp       : per (energy bin, compact material) one 32-byte record
 //               {a_tot, a_Co, a_Ra, b_tot | b_Co, b_Ra, pmax(bin+1), 0}  -- one aligned 32-B fetch where the
 //               reference reads 2 x float3 from two 7.2 MB tables plus pmax from a third (K.cu:268-269,336).
@@ -24,44 +25,71 @@ namespace mcgpu {
 
 enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
 constexpr int kTrackBlockThreads = 512;   // 8 waves per workgroup
-constexpr int kMaxBricks = 32768;         // LDS budget of the brick grid (bytes)
+constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
+constexpr int kSlotWords = 13;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
+constexpr int kNumStats = 16;             // scheduler counters of the diagnostic build
 
-struct TrackArgs {
-  // geometry
-  const void* vol;
-  const float* palette;  // float2 pairs {density, bits(mat_c)}
-  int vol_kind, palette_size;
-  const unsigned char* bricks;  // brick grid: palette index of a homogeneous brick, 0xFF = mixed (u8 volumes only)
-  int brick_shift, brick_nx, brick_nxy, brick_count;
-  int nx, ny, nz, nxy;
-  float inv_vs[3];
-  float bbox[3];
-  // energy grid and cross sections
-  float e0, ide;
-  int num_values, nmat;
-  const float* woodcock;  // float2[num_values]
-  const float* mfp;       // 8 floats per (bin*nmat + mc)
+// Byte offsets of the kernel's dynamic LDS image (track_common.inc: stage_tables).  Sized for the materials and
+// palette entries actually in use so that three 512-thread workgroups fit one CU's 160 KiB.
+struct LdsLayout {
+  int fco, uico, fj0;        // float[kMaxShells * nmat] each, index shell * nmat + material
+  int nosc;                  // int[nmat]
+  int espc, cutoff, alias;   // float[nbins + 1], float[nbins + 1], short[nbins + 1]
+  int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
+  int brick;                 // u8[brick_bytes]
+  int slots;                 // u32[kSlotWords][kTrackBlockThreads] (FAST kernel only)
+  int total;                 // bytes
+};
+
+// Tables the kernels touch rarely (staging, Rayleigh sampling): kept behind one pointer so that the launch
+// arguments -- which the compiler keeps in scalar registers for the whole kernel -- stay within the SGPR file.
+struct TrackCold {
   // Rayleigh / Compton sampling tables (compact material index)
   const float *xco, *pco, *aco, *bco;
   const unsigned char *itl, *itu;
   const float *fco, *uico, *fj0;  // [shell*nmat + mc]
   const int* noscco;              // [nmat]
   // spectrum
-  int nbins;
   const float *espc, *cutoff;
   const short* alias;
-  // pose of this projection
-  SourcePose src;
-  DetectorPose det;
+  const unsigned char* bricks;  // brick grid, two 4-bit codes per byte (u8 volumes only)
+  int brick_palette[16];        // palette index of brick code c (c < 15)
+};
+
+struct TrackArgs {
+  // geometry
+  const void* vol;
+  const float* palette;  // float2 pairs {density, bits(mat_c)}
+  int vol_kind, palette_size;
+  int brick_shift, brick_nx, brick_nxy, brick_bytes;
+  float brick_scale[3];  // inv_vs / 2^brick_shift: position -> brick coordinate
+  int nx, ny, nz, nxy;
+  float inv_vs[3];
+  float bbox[3];
+  float bbox_hi[3];  // FAST: largest coordinate still inside: <= bbox - EPS and mapping into the last voxel / brick
+  LdsLayout lds;
+  // energy grid and cross sections
+  float e0, ide;
+  int num_values, nmat;
+  const float* woodcock;  // float2[num_values]
+  const float* mfp;       // 8 floats per (bin*nmat + mc)
+  const TrackCold* cold;
+  int nbins;
+  // pose of this projection (device-resident arrays of all projections, uploaded once)
+  const SourcePose* src;
+  const DetectorPose* det;
   // tally
   unsigned long long* image;
   // schedule
   int seed, hpt;
   unsigned long long first, count;
   unsigned int stream_key;  // FAST: projection index mixed into the Philox key
-  // parked lanes per wave64 that trigger a batched service of that kind
+  // parked histories per wave64 that trigger a batched service of that kind
   int thresh_compton, thresh_rayleigh, thresh_new;
-  unsigned long long* stats;  // diagnostic build only (8 counters), else null
+  // FAST kernel: service everything pending when fewer lanes than `flyable_low` can fly; bring parked/flying
+  // histories in/out of the LDS slots once `swap_batch` lanes have parked
+  int flyable_low, swap_batch;
+  unsigned long long* stats;  // diagnostic build only (kNumStats counters), else null
   unsigned long long* work_counter;  // FAST: next unassigned history offset (zeroed before each launch)
 };
 

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -21,7 +22,6 @@ namespace mcgpu {
 
 hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
-int occupancy_track_compat(const TrackArgs& args);
 int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
@@ -49,9 +49,15 @@ struct DeviceModel {
   int vol_kind = kVolU8, palette_size = 0;
   float* palette = nullptr;
   unsigned char* bricks = nullptr;
-  int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, bricks_mixed = 0;
+  int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, brick_bytes = 0, bricks_mixed = 0;
+  int brick_palette[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int num_spectrum_bins = 0;
+  LdsLayout lds;
+  TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
+  SourcePose* src_all = nullptr;  // [num_projections]
+  DetectorPose* det_all = nullptr;
   int resident_fast = 0;  // workgroups per CU (occupancy query), 0 = not asked yet
-  unsigned long long* stats = nullptr;  // 8 scheduler counters of the diagnostic build
+  unsigned long long* stats = nullptr;  // kNumStats scheduler counters of the diagnostic build
   unsigned long long* work_counter = nullptr;  // history-id dispenser of the FAST kernel
   float *woodcock = nullptr, *mfp = nullptr;
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
@@ -187,12 +193,29 @@ void upload_model(mcgpu_ctx& C, int device_id) {
           else if (first[b] != v) mixed[b] = 1;
         }
       }
-    std::vector<unsigned char> bricks(D.brick_count);
+    // 4-bit codes: the 15 most frequent palette entries among homogeneous bricks get codes 0..14, every other
+    // brick (mixed, or a rarer homogeneous one) is 0xF = "read the voxel"
+    std::vector<long> homogeneous(256, 0);
+    for (int b = 0; b < D.brick_count; ++b)
+      if (!mixed[b] && first[b] >= 0) ++homogeneous[first[b]];
+    std::vector<int> order(256);
+    for (int i = 0; i < 256; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return homogeneous[a] > homogeneous[b]; });
+    int code_of[256];
+    for (int i = 0; i < 256; ++i) code_of[i] = 0xF;
+    for (int c = 0; c < 15; ++c) {
+      D.brick_palette[c] = 0;
+      if (homogeneous[order[c]] > 0) { code_of[order[c]] = c; D.brick_palette[c] = order[c]; }
+    }
+    D.brick_palette[15] = 0;
+    D.brick_bytes = (D.brick_count + 1) / 2;
+    std::vector<unsigned char> bricks(D.brick_bytes, 0xFF);
     D.bricks_mixed = 0;
     for (int b = 0; b < D.brick_count; ++b) {
-      const bool m = mixed[b] || first[b] < 0 || first[b] >= 0xFF;
-      bricks[b] = m ? 0xFF : (unsigned char)first[b];
-      D.bricks_mixed += m;
+      const int code = (mixed[b] || first[b] < 0) ? 0xF : code_of[first[b]];
+      D.bricks_mixed += (code == 0xF);
+      const int sh = (b & 1) * 4;
+      bricks[b >> 1] = (unsigned char)((bricks[b >> 1] & ~(0xF << sh)) | (code << sh));
     }
     D.bricks = D.put(bricks);
   } else {
@@ -248,10 +271,44 @@ void upload_model(mcgpu_ctx& C, int device_id) {
   D.espc = D.put(std::vector<float>(H.spectrum.espc, H.spectrum.espc + kMaxSpectrumBins));
   D.cutoff = D.put(std::vector<float>(H.spectrum.cutoff, H.spectrum.cutoff + kMaxSpectrumBins));
   D.alias = D.put(std::vector<short>(H.spectrum.alias, H.spectrum.alias + kMaxSpectrumBins));
+  // ---- LDS image of the kernels (byte offsets; track_common.inc: stage_tables)
+  {
+    LdsLayout& Y = D.lds;
+    int off = 0;
+    auto take = [&](int bytes, int align) { off = (off + align - 1) / align * align; const int at = off; off += bytes; return at; };
+    const int ns = std::min(H.spectrum.num_bins + 1, kMaxSpectrumBins) + 1;
+    Y.fco = take(kMaxShells * nmat * 4, 16);
+    Y.uico = take(kMaxShells * nmat * 4, 16);
+    Y.fj0 = take(kMaxShells * nmat * 4, 16);
+    Y.nosc = take(std::max(nmat, 1) * 4, 16);
+    Y.espc = take(ns * 4, 16);
+    Y.cutoff = take(ns * 4, 16);
+    Y.alias = take(ns * 2, 16);
+    Y.pal = take(D.vol_kind == kVolU8 ? (16 + D.palette_size) * 8 : 0, 16);
+    Y.brick = take(D.vol_kind == kVolU8 ? D.brick_bytes : 0, 16);
+    Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
+    take(kSlotWords * kTrackBlockThreads * 4, 16);
+    Y.total = (off + 15) / 16 * 16;
+  }
+  D.num_spectrum_bins = H.spectrum.num_bins;
+  {
+    TrackCold cold;
+    memset(&cold, 0, sizeof cold);
+    cold.xco = D.xco; cold.pco = D.pco; cold.aco = D.aco; cold.bco = D.bco; cold.itl = D.itl; cold.itu = D.itu;
+    cold.fco = D.fco; cold.uico = D.uico; cold.fj0 = D.fj0; cold.noscco = D.noscco;
+    cold.espc = D.espc; cold.cutoff = D.cutoff; cold.alias = D.alias;
+    cold.bricks = D.bricks;
+    for (int c = 0; c < 16; ++c) cold.brick_palette[c] = D.brick_palette[c];
+    D.cold = D.put(std::vector<TrackCold>(1, cold));
+    D.src_all = D.put(H.source);
+    D.det_all = D.put(H.detector);
+  }
   HIP_TRY(hipEventCreate(&D.ev_start));
   HIP_TRY(hipEventCreate(&D.ev_stop));
   HIP_TRY(hipDeviceSynchronize());
 }
+
+void require(bool ok, int code, const char* msg) { if (!ok) throw Error(code, msg); }
 
 TrackArgs make_args(const mcgpu_ctx& C, int p) {
   const HostModel& H = C.host;
@@ -259,26 +316,37 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   TrackArgs A;
   memset(&A, 0, sizeof A);
   A.vol = D.vol; A.palette = D.palette; A.vol_kind = D.vol_kind; A.palette_size = D.palette_size;
-  A.bricks = D.bricks; A.brick_shift = D.brick_shift; A.brick_nx = D.brick_n[0]; A.brick_nxy = D.brick_n[0] * D.brick_n[1];
-  A.brick_count = D.vol_kind == kVolU8 ? D.brick_count : 0;
+  A.brick_shift = D.brick_shift; A.brick_nx = D.brick_n[0]; A.brick_nxy = D.brick_n[0] * D.brick_n[1];
+  A.brick_bytes = D.vol_kind == kVolU8 ? D.brick_bytes : 0;
+  A.lds = D.lds;
   A.nx = H.voxels.n[0]; A.ny = H.voxels.n[1]; A.nz = H.voxels.n[2]; A.nxy = A.nx * A.ny;
-  for (int k = 0; k < 3; ++k) { A.inv_vs[k] = H.voxels.inv_voxel_size[k]; A.bbox[k] = H.voxels.size_bbox[k]; }
+  for (int k = 0; k < 3; ++k) {
+    A.inv_vs[k] = H.voxels.inv_voxel_size[k];
+    A.bbox[k] = H.voxels.size_bbox[k];
+    A.brick_scale[k] = H.voxels.inv_voxel_size[k] / (float)(1 << D.brick_shift);  // exact: a power-of-two scaling
+    // upper clamp of the FAST kernel: bbox - EPS_SOURCE (MC-GPU_v1.3.h:87), lowered until it indexes the last voxel
+    float hi = A.bbox[k] - 0.000015f;
+    while ((int)(hi * A.inv_vs[k]) > H.voxels.n[k] - 1) hi = std::nextafter(hi, 0.0f);
+    A.bbox_hi[k] = hi;
+  }
+  require((long long)A.nx * A.ny < (1LL << 24) && (long long)H.voxels.count() < (1LL << 31), -2,
+          "!!ERROR!! voxel grid too large for the 32-bit voxel index of the kernel");
   A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat;
   A.woodcock = D.woodcock; A.mfp = D.mfp;
-  A.xco = D.xco; A.pco = D.pco; A.aco = D.aco; A.bco = D.bco; A.itl = D.itl; A.itu = D.itu;
-  A.fco = D.fco; A.uico = D.uico; A.fj0 = D.fj0; A.noscco = D.noscco;
-  A.nbins = H.spectrum.num_bins; A.espc = D.espc; A.cutoff = D.cutoff; A.alias = D.alias;
-  A.src = H.source[p]; A.det = H.detector[p];
+  A.cold = D.cold;
+  A.nbins = H.spectrum.num_bins;
+  A.src = D.src_all + p; A.det = D.det_all + p;
   A.stream_key = (unsigned)p;
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 20);
-  A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 6);
-  A.thresh_new = env_int("MCGPU_THRESH_NEW", 24);
+  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 40);
+  A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 10);
+  A.thresh_new = env_int("MCGPU_THRESH_NEW", 40);
+  A.flyable_low = std::max(1, env_int("MCGPU_FLYABLE_LOW", 24));
+  A.swap_batch = std::max(1, env_int("MCGPU_SWAP_BATCH", 8));
   return A;
 }
 
-void require(bool ok, int code, const char* msg) { if (!ok) throw Error(code, msg); }
 
 const void* host_table(mcgpu_ctx& C, const std::string& name, size_t& bytes) {
   HostModel& H = C.host;
@@ -395,6 +463,8 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "brick_count") *value = ctx->dev.brick_count;
   else if (k == "bricks_mixed") *value = ctx->dev.bricks_mixed;
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
+  else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
+  else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots;
   else return set_error(-2, std::string("unknown integer key: ") + key);
   return 0;
   ABI_END
@@ -499,7 +569,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       HIP_TRY(hipMemsetAsync(D.work_counter, 0, 8, stream));
       A.work_counter = D.work_counter;
       if (mode == MCGPU_MODE_FAST_STATS) {
-        if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(8, 0ULL));
+        if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats, 0ULL));
         A.stats = D.stats;
         HIP_TRY(launch_track_stats(A, (int)std::min(want, resident), stream));
       } else {
@@ -513,17 +583,21 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
   ABI_END
 }
 
-int mcgpu_scheduler_stats(mcgpu_ctx* ctx, unsigned long long* out8, int reset) {
+int mcgpu_scheduler_stats_ex(mcgpu_ctx* ctx, unsigned long long* out, int capacity, int reset) {
   ABI_BEGIN
-  require(ctx && ctx->has_device && out8, -1, "!!ERROR!! mcgpu_scheduler_stats: bad argument");
+  require(ctx && ctx->has_device && out && capacity > 0, -1, "!!ERROR!! mcgpu_scheduler_stats: bad argument");
   HIP_TRY(hipSetDevice(ctx->dev.device_id));
-  if (!ctx->dev.stats) { for (int k = 0; k < 8; ++k) out8[k] = 0; return 0; }
+  const int n = std::min(capacity, kNumStats);
+  for (int k = 0; k < capacity; ++k) out[k] = 0;
+  if (!ctx->dev.stats) return 0;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out8, ctx->dev.stats, 64, hipMemcpyDeviceToHost));
-  if (reset) HIP_TRY(hipMemset(ctx->dev.stats, 0, 64));
+  HIP_TRY(hipMemcpy(out, ctx->dev.stats, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(ctx->dev.stats, 0, (size_t)kNumStats * 8));
   return 0;
   ABI_END
 }
+
+int mcgpu_scheduler_stats(mcgpu_ctx* ctx, unsigned long long* out8, int reset) { return mcgpu_scheduler_stats_ex(ctx, out8, 8, reset); }
 
 int mcgpu_last_kernel_ms(mcgpu_ctx* ctx, float* ms) {
   ABI_BEGIN

@@ -1,6 +1,6 @@
 // track_fast.hip -- FAST (production) personality of the photon-history kernel.
 #define MC_COMPAT 0
-#include "track_kernel.inc"
+#include "track_pool.inc"
 
 namespace mcgpu {
 namespace {

@@ -3,4 +3,4 @@
 // 4/5 Rayleigh rounds / lanes, 6/7 tally+source rounds / lanes.
 #define MC_COMPAT 0
 #define MC_STATS 1
-#include "track_kernel.inc"
+#include "track_pool.inc"

@@ -24,7 +24,7 @@ EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
 ABI_SYMBOLS = (
     "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
-    "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
+    "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
 )
 
@@ -66,6 +66,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_launch_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, vp]
     lib.mcgpu_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mcgpu_scheduler_stats.argtypes = [vp, C.POINTER(cull), ci]
+    lib.mcgpu_scheduler_stats_ex.argtypes = [vp, C.POINTER(cull), ci, ci]
     lib.mcgpu_clear_image.argtypes = [vp, vp, vp]
     lib.mcgpu_run_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, C.POINTER(C.c_double), C.POINTER(cull)]
     lib.mcgpu_write_projection.argtypes = [vp, ci, vp, cull, C.c_double, cp]
@@ -180,9 +181,10 @@ class Context:
 
     def scheduler_stats(self, reset: bool = True) -> dict:
         """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""
-        out = (C.c_ulonglong * 8)()
-        _check(self.lib.mcgpu_scheduler_stats(self.h, out, int(reset)))
-        names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes")
+        out = (C.c_ulonglong * 12)()
+        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 12, int(reset)))
+        names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
+                 "scheduling_points", "take_rounds", "take_lanes", "drain_points")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

@@ -92,6 +92,9 @@ int mcgpu_last_kernel_ms(mcgpu_ctx *ctx, float *ms);
 /* Scheduler statistics accumulated by MCGPU_MODE_FAST_STATS launches: out8 = {wave loop iterations, sum of flying
  * lanes, Compton rounds, Compton lanes, Rayleigh rounds, Rayleigh lanes, tally+source rounds, their lanes}. */
 int mcgpu_scheduler_stats(mcgpu_ctx *ctx, unsigned long long *out8, int reset);
+/* The same with the full counter set (up to 16): 8 = scheduling points, 9/10 = register<->LDS-slot exchange rounds /
+ * lanes that bring a flying history in, 11 = scheduling points in drain mode. */
+int mcgpu_scheduler_stats_ex(mcgpu_ctx *ctx, unsigned long long *out, int capacity, int reset);
 /* hipMemsetAsync of an image buffer (init_image_array_GPU, MC-GPU_kernel_v1.3.cu:56-72). */
 int mcgpu_clear_image(mcgpu_ctx *ctx, void *image_dev, void *hip_stream);
 

@@ -1,18 +1,31 @@
-"""Diagnostic (GPU): scheduler statistics of the FAST kernel on the bench workload for a set of thresholds."""
-import os, sys, json
+"""Diagnostic (GPU): scheduler statistics of the FAST kernel on the bench workload for a set of tuning parameters.
+usage: sched_stats.py [input.in] [histories] ["tC,tR,tN,flyable_low,swap_batch" ...]"""
+import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cases
 eng = cases.pkg.engine
 inp = sys.argv[1] if len(sys.argv) > 1 else "/tmp/mcgpu_bench_512_894/input.in"
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
+configs = sys.argv[3:] or [""]
+KEYS = ("MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH")
 with eng.create(inp, device=0) as ctx:
-    img, secs, done = ctx.run_projection(0, n, mode="stats", seed=42)
-    s = ctx.scheduler_stats()
-    it = s["iterations"]
-    print(json.dumps({"thresholds": [os.environ.get(k) for k in ("MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW")],
-                      "histories": done, "wave_iterations_per_history": it / done, "mean_flying_lanes": s["flying_lanes"] / it,
-                      "compton_lanes_per_round": s["compton_lanes"] / max(s["compton_rounds"], 1), "compton_rounds_per_history": s["compton_rounds"] / done,
-                      "rayleigh_lanes_per_round": s["rayleigh_lanes"] / max(s["rayleigh_rounds"], 1), "rayleigh_rounds_per_history": s["rayleigh_rounds"] / done,
-                      "new_lanes_per_round": s["new_lanes"] / max(s["new_rounds"], 1), "new_rounds_per_history": s["new_rounds"] / done,
-                      "bricks_mixed": ctx.geti("bricks_mixed"), "brick_count": ctx.geti("brick_count"), "blocks_per_cu": ctx.geti("blocks_per_cu")}))
+    for cfg in configs:
+        for k in KEYS:
+            os.environ.pop(k, None)
+        for k, v in zip(KEYS, [x for x in cfg.split(",") if x]):
+            os.environ[k] = v
+        ctx.run_projection(0, n, mode="fast", seed=42)  # warm
+        _, secs, _ = ctx.run_projection(0, n, mode="fast", seed=42)
+        img, _, done = ctx.run_projection(0, n, mode="stats", seed=42)
+        s = ctx.scheduler_stats()
+        it = max(s["iterations"], 1)
+        print(json.dumps({"cfg": cfg, "Mhist_per_s": round(done / secs / 1e6, 1), "iter_per_hist": round(it / done, 4),
+                          "mean_flying": round(s["flying_lanes"] / it, 2),
+                          "compton": [round(s["compton_lanes"] / max(s["compton_rounds"], 1), 1), round(s["compton_rounds"] / done, 5)],
+                          "rayleigh": [round(s["rayleigh_lanes"] / max(s["rayleigh_rounds"], 1), 1), round(s["rayleigh_rounds"] / done, 5)],
+                          "new": [round(s["new_lanes"] / max(s["new_rounds"], 1), 1), round(s["new_rounds"] / done, 5)],
+                          "sched_points_per_hist": round(s["scheduling_points"] / done, 4),
+                          "take": [round(s["take_lanes"] / max(s["take_rounds"], 1), 1), round(s["take_rounds"] / done, 5)],
+                          "drain_frac": round(s["drain_points"] / max(s["scheduling_points"], 1), 3),
+                          "blocks_per_cu": ctx.geti("blocks_per_cu"), "lds": ctx.geti("lds_bytes_fast")}))
