@@ -177,7 +177,9 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     const int nx = H.voxels.n[0], ny = H.voxels.n[1], nz = H.voxels.n[2];
     int k = 2;
     auto nb = [&](int n, int sh) { return (n + (1 << sh) - 1) >> sh; };
-    while ((long)nb(nx, k) * nb(ny, k) * nb(nz, k) > kMaxBricks) ++k;
+    const char* mb = getenv("MCGPU_MAX_BRICKS");  // tuning knob: a coarser grid frees LDS
+    const long max_bricks = mb ? std::min<long>(std::max<long>(atol(mb), 1), kMaxBricks) : kMaxBricks;
+    while ((long)nb(nx, k) * nb(ny, k) * nb(nz, k) > max_bricks) ++k;
     D.brick_shift = k;
     D.brick_n[0] = nb(nx, k); D.brick_n[1] = nb(ny, k); D.brick_n[2] = nb(nz, k);
     D.brick_count = D.brick_n[0] * D.brick_n[1] * D.brick_n[2];
@@ -339,10 +341,10 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.stream_key = (unsigned)p;
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 40);
-  A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 10);
-  A.thresh_new = env_int("MCGPU_THRESH_NEW", 40);
-  A.flyable_low = std::max(1, env_int("MCGPU_FLYABLE_LOW", 24));
+  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 32);
+  A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 8);
+  A.thresh_new = env_int("MCGPU_THRESH_NEW", 32);
+  A.flyable_low = std::max(1, env_int("MCGPU_FLYABLE_LOW", 16));
   A.swap_batch = std::max(1, env_int("MCGPU_SWAP_BATCH", 8));
   return A;
 }

@@ -17,7 +17,7 @@ MODE_FAST, MODE_COMPAT, MODE_FAST_STATS = 0, 1, 2
 _MODES = {"fast": MODE_FAST, "compat": MODE_COMPAT, "stats": MODE_FAST_STATS, MODE_FAST: MODE_FAST, MODE_COMPAT: MODE_COMPAT,
           MODE_FAST_STATS: MODE_FAST_STATS}
 
-LIB_PATH = Path(__file__).resolve().parent / "libmcgpu_amd.so"
+LIB_PATH = Path(os.environ.get("MCGPU_AMD_LIB", Path(__file__).resolve().parent / "libmcgpu_amd.so"))  # override: A/B builds
 EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
 
 # every symbol declared in include/mcgpu_amd.h

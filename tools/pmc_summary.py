@@ -5,7 +5,7 @@ out = {}
 for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=True):
     acc = {}
     for row in csv.DictReader(open(f)):
-        if "track_kernel" not in row["Kernel_Name"]:
+        if "track_" not in row["Kernel_Name"] or "kernel" not in row["Kernel_Name"]:
             continue
         acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
