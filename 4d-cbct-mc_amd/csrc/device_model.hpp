@@ -28,6 +28,7 @@ constexpr int kTrackBlockThreads = 512;   // 8 waves per workgroup
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kSlotWords = 13;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kNumStats = 16;             // scheduler counters of the diagnostic build
+constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
 
 // Byte offsets of the kernel's dynamic LDS image (track_common.inc: stage_tables).  Sized for the materials and
 // palette entries actually in use so that three 512-thread workgroups fit one CU's 160 KiB.
@@ -37,6 +38,7 @@ struct LdsLayout {
   int espc, cutoff, alias;   // float[nbins + 1], float[nbins + 1], short[nbins + 1]
   int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
   int brick;                 // u8[brick_bytes]
+  int dose_mat;              // u64[25][2]: per-workgroup material-dose accumulators, flushed at kernel end
   int slots;                 // u32[kSlotWords][kTrackBlockThreads] (FAST kernel only)
   int total;                 // bytes
 };
@@ -54,6 +56,11 @@ struct TrackCold {
   const short* alias;
   const unsigned char* bricks;  // brick grid, two 4-bit codes per byte (u8 volumes only)
   int brick_palette[16];        // palette index of brick code c (c < 15)
+  // dose tallies (K.cu:418-443, :1547-1563); buffers live for the whole simulation (all projections accumulate)
+  unsigned long long* dose_voxels;     // ulonglong2 {Edep * 100, Edep^2} per ROI voxel, x fastest; null = tally off
+  unsigned long long* dose_materials;  // ulonglong2 per material number (25 entries); null = tally off
+  int dose_roi[6];                     // 0-based inclusive xmin,xmax,ymin,ymax,zmin,zmax
+  int material_of_compact[25];         // material number - 1 of compact material index mc
 };
 
 struct TrackArgs {
@@ -89,6 +96,7 @@ struct TrackArgs {
   // FAST kernel: service everything pending when fewer lanes than `flyable_low` can fly; bring parked/flying
   // histories in/out of the LDS slots once `swap_batch` lanes have parked
   int flyable_low, swap_batch;
+  int dose_flags;             // bit 0: material dose tally, bit 1: voxel dose tally (TrackCold holds the buffers)
   unsigned long long* stats;  // diagnostic build only (kNumStats counters), else null
   unsigned long long* work_counter;  // FAST: next unassigned history offset (zeroed before each launch)
 };

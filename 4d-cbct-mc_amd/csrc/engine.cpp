@@ -54,6 +54,10 @@ struct DeviceModel {
   int num_spectrum_bins = 0;
   LdsLayout lds;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
+  unsigned long long* dose_voxels = nullptr;     // ulonglong2 per ROI voxel (null: tally off)
+  unsigned long long* dose_materials = nullptr;  // ulonglong2 x 25 (null: tally off)
+  size_t dose_roi_voxels = 0;
+  int dose_flags = 0;
   SourcePose* src_all = nullptr;  // [num_projections]
   DetectorPose* det_all = nullptr;
   int resident_fast = 0;  // workgroups per CU (occupancy query), 0 = not asked yet
@@ -288,6 +292,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.alias = take(ns * 2, 16);
     Y.pal = take(D.vol_kind == kVolU8 ? (16 + D.palette_size) * 8 : 0, 16);
     Y.brick = take(D.vol_kind == kVolU8 ? D.brick_bytes : 0, 16);
+    Y.dose_mat = take(2 * kMaxMaterials * 8, 16);
     Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
     take(kSlotWords * kTrackBlockThreads * 4, 16);
     Y.total = (off + 15) / 16 * 16;
@@ -301,6 +306,23 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     cold.espc = D.espc; cold.cutoff = D.cutoff; cold.alias = D.alias;
     cold.bricks = D.bricks;
     for (int c = 0; c < 16; ++c) cold.brick_palette[c] = D.brick_palette[c];
+    // dose tallies (read_input :1868-1893, init_CUDA_device :2636-2657,2694-2720)
+    const SimConfig& cfg = H.cfg;
+    if (cfg.flag_material_dose == 1) {
+      D.dose_materials = D.put(std::vector<unsigned long long>(2 * kMaxMaterials, 0ULL));
+      D.dose_flags |= kDoseMaterials;
+    }
+    if (cfg.dose_roi[1] > -1) {
+      D.dose_roi_voxels = (size_t)(cfg.dose_roi[1] - cfg.dose_roi[0] + 1) * (size_t)(cfg.dose_roi[3] - cfg.dose_roi[2] + 1) *
+                          (size_t)(cfg.dose_roi[5] - cfg.dose_roi[4] + 1);
+      D.dose_voxels = D.put(std::vector<unsigned long long>(2 * D.dose_roi_voxels, 0ULL));
+      D.dose_flags |= kDoseVoxels;
+    }
+    cold.dose_voxels = D.dose_voxels;
+    cold.dose_materials = D.dose_materials;
+    for (int k = 0; k < 6; ++k) cold.dose_roi[k] = cfg.dose_roi[k];
+    for (int m = 0; m < kMaxMaterials; ++m)
+      if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
     D.cold = D.put(std::vector<TrackCold>(1, cold));
     D.src_all = D.put(H.source);
     D.det_all = D.put(H.detector);
@@ -339,6 +361,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.nbins = H.spectrum.num_bins;
   A.src = D.src_all + p; A.det = D.det_all + p;
   A.stream_key = (unsigned)p;
+  A.dose_flags = D.dose_flags;
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 32);
@@ -655,6 +678,74 @@ int mcgpu_write_projection(mcgpu_ctx* ctx, int p, const uint64_t* image_host, un
   require(total_histories > 0, -2, "!!ERROR!! mcgpu_write_projection: zero histories");
   const std::string name = file_name ? std::string(file_name) : projection_file_name(ctx->host, p);
   write_projection_ascii(ctx->host, p, image_host, total_histories, seconds, name);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_dose_info(const mcgpu_ctx* ctx, int* flags, int roi6[6], size_t* roi_voxels) {
+  ABI_BEGIN
+  require(ctx != nullptr, -1, "!!ERROR!! mcgpu_dose_info: null context");
+  const SimConfig& c = ctx->host.cfg;
+  const bool vox = c.dose_roi[1] > -1;
+  if (flags) *flags = (c.flag_material_dose == 1 ? 1 : 0) | (vox ? 2 : 0);
+  if (roi6) for (int k = 0; k < 6; ++k) roi6[k] = c.dose_roi[k];
+  if (roi_voxels)
+    *roi_voxels = vox ? (size_t)(c.dose_roi[1] - c.dose_roi[0] + 1) * (size_t)(c.dose_roi[3] - c.dose_roi[2] + 1) * (size_t)(c.dose_roi[5] - c.dose_roi[4] + 1) : 0;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_dose_read(mcgpu_ctx* ctx, uint64_t* voxels_out, uint64_t* materials_out) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_dose_read: the context has no device");
+  DeviceModel& D = ctx->dev;
+  HIP_TRY(hipSetDevice(D.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  if (voxels_out) {
+    require(D.dose_voxels != nullptr, -2, "!!ERROR!! mcgpu_dose_read: the voxel dose tally is disabled in the input file");
+    HIP_TRY(hipMemcpy(voxels_out, D.dose_voxels, D.dose_roi_voxels * 16, hipMemcpyDeviceToHost));
+  }
+  if (materials_out) {
+    require(D.dose_materials != nullptr, -2, "!!ERROR!! mcgpu_dose_read: the material dose tally is disabled in the input file");
+    HIP_TRY(hipMemcpy(materials_out, D.dose_materials, (size_t)kMaxMaterials * 16, hipMemcpyDeviceToHost));
+  }
+  return 0;
+  ABI_END
+}
+
+int mcgpu_dose_clear(mcgpu_ctx* ctx) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_dose_clear: the context has no device");
+  DeviceModel& D = ctx->dev;
+  HIP_TRY(hipSetDevice(D.device_id));
+  if (D.dose_voxels) HIP_TRY(hipMemset(D.dose_voxels, 0, D.dose_roi_voxels * 16));
+  if (D.dose_materials) HIP_TRY(hipMemset(D.dose_materials, 0, (size_t)kMaxMaterials * 16));
+  return 0;
+  ABI_END
+}
+
+int mcgpu_write_dose_report(mcgpu_ctx* ctx, const uint64_t* voxels, const uint64_t* materials, unsigned long long histories_per_projection,
+                            double seconds, char* log, size_t log_bytes) {
+  ABI_BEGIN
+  require(ctx != nullptr && histories_per_projection > 0, -1, "!!ERROR!! mcgpu_write_dose_report: bad argument");
+  std::string text;
+  if (voxels) {
+    require(ctx->host.cfg.dose_roi[1] > -1, -2, "!!ERROR!! mcgpu_write_dose_report: the voxel dose tally is disabled in the input file");
+    write_voxel_dose_report(ctx->host, voxels, histories_per_projection, seconds, text);
+  }
+  if (materials) {
+    double mass[kMaxMaterials];
+    material_masses(ctx->host, mass);
+    format_materials_dose_report(ctx->host, materials, histories_per_projection, mass, text);
+  }
+  if (log && log_bytes > 0) {
+    const size_t n = std::min(text.size(), log_bytes - 1);
+    memcpy(log, text.data(), n);
+    log[n] = '\0';
+  } else {
+    fputs(text.c_str(), stdout);
+    fflush(stdout);
+  }
   return 0;
   ABI_END
 }

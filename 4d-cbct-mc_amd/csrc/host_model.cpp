@@ -794,6 +794,9 @@ void load_model(const std::string& input_path, HostModel& m) {
   load_spectrum(m.cfg.file_spectrum, m.spectrum);
   build_ct_trajectory(m);
   load_voxel_file(m.cfg.file_voxels, m.voxels);
+  // the dose ROI may be given larger than the volume: clip its upper corner (load_voxels, :2058-2064)
+  if (m.cfg.dose_roi[1] > -1)
+    for (int ax = 0; ax < 3; ++ax) m.cfg.dose_roi[2 * ax + 1] = std::min(m.cfg.dose_roi[2 * ax + 1], m.voxels.n[ax] - 1);
   load_material_files(m.cfg.file_materials, m.voxels, m.mat);
   // consistency check of main() (:565-577)
   const float emax = m.mat.e0 + (m.mat.num_values - 1) / m.mat.ide;

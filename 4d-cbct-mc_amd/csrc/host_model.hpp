@@ -135,6 +135,14 @@ std::string projection_file_name(const HostModel& m, int p);
 size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, unsigned long long total_histories,
                               double seconds, const std::string& file_name, int n_threads = 0);
 
+// Dose reports (report_voxels_dose :2976-3199, report_materials_dose :3214-3262, material masses :579-585); the text the
+// reference prints to stdout is appended to `log`.
+void material_masses(const HostModel& m, double mass[kMaxMaterials]);
+void write_voxel_dose_report(const HostModel& m, const uint64_t* voxels_edep, unsigned long long histories_per_projection,
+                             double seconds, std::string& log);
+void format_materials_dose_report(const HostModel& m, const uint64_t* materials_dose, unsigned long long histories_per_projection,
+                                  const double* mass, std::string& log);
+
 // Fast text/binary voxel writers (cbctmc/mc/voxel_data.pyx + mcgpu_geometry header fields)
 size_t write_voxel_file(const std::string& path, const int n[3], const float spacing_cm[3], const uint8_t* material,
                         const float* density, bool gzip);

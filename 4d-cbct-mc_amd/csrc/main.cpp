@@ -111,6 +111,25 @@ int main(int argc, char** argv) {
     if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
     fflush(stdout);
   }
+  // dose tallies accumulate over all projections (MC-GPU_v1.3.cu:1062-1165): sum the devices, report once
+  int dose_flags = 0;
+  size_t roi_voxels = 0;
+  mcgpu_dose_info(ctx[0], &dose_flags, nullptr, &roi_voxels);
+  if (dose_flags != 0) {
+    std::vector<uint64_t> vox(dose_flags & 2 ? 2 * roi_voxels : 0), mat(dose_flags & 1 ? 50 : 0), tmp_v(vox.size()), tmp_m(mat.size());
+    for (int g = 0; g < ngpu; ++g) {
+      if (mcgpu_dose_read(ctx[g], vox.empty() ? nullptr : tmp_v.data(), mat.empty() ? nullptr : tmp_m.data()) != 0) {
+        printf("\n\n   %s\n\n", mcgpu_last_error());
+        return 253;
+      }
+      for (size_t i = 0; i < vox.size(); ++i) vox[i] += tmp_v[i];
+      for (size_t i = 0; i < mat.size(); ++i) mat[i] += tmp_m[i];
+    }
+    if (mcgpu_write_dose_report(ctx[0], vox.empty() ? nullptr : vox.data(), mat.empty() ? nullptr : mat.data(), total, now_s() - t_begin, nullptr, 0) != 0) {
+      printf("\n\n   %s\n\n", mcgpu_last_error());
+      return 253;
+    }
+  }
   for (auto* c : ctx) mcgpu_destroy(c);
   const double t_all = now_s() - t_begin;
   printf("\n\n\n    -- SIMULATION FINISHED!\n\n          >>> Execution time including initialization, transport and report: %.3f s.\n"

@@ -25,7 +25,8 @@ ABI_SYMBOLS = (
     "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
-    "mcgpu_write_projection", "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
+    "mcgpu_write_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
+    "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
 )
 
 
@@ -70,6 +71,10 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_clear_image.argtypes = [vp, vp, vp]
     lib.mcgpu_run_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, C.POINTER(C.c_double), C.POINTER(cull)]
     lib.mcgpu_write_projection.argtypes = [vp, ci, vp, cull, C.c_double, cp]
+    lib.mcgpu_dose_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_size_t)]
+    lib.mcgpu_dose_read.argtypes = [vp, vp, vp]
+    lib.mcgpu_dose_clear.argtypes = [vp]
+    lib.mcgpu_write_dose_report.argtypes = [vp, vp, vp, cull, C.c_double, cp, C.c_size_t]
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
@@ -216,6 +221,35 @@ class Context:
         _check(self.lib.mcgpu_write_projection(self.h, p, img.ctypes.data, int(total_histories), float(seconds),
                                                file_name.encode() if file_name else None))
         return file_name or self.projection_file_name(p)
+
+    # -- dose tallies (SECTION DOSE DEPOSITION of the input file)
+    def dose_info(self):
+        """(flags, roi6, roi_shape_zyx): flags bit 0 = material tally, bit 1 = voxel tally."""
+        flags, roi, n = C.c_int(), (C.c_int * 6)(), C.c_size_t()
+        _check(self.lib.mcgpu_dose_info(self.h, C.byref(flags), roi, C.byref(n)))
+        r = list(roi)
+        shape = (r[5] - r[4] + 1, r[3] - r[2] + 1, r[1] - r[0] + 1) if flags.value & 2 else (0, 0, 0)
+        return flags.value, r, shape
+
+    def dose_read(self):
+        """(voxels uint64[Dz, Dy, Dx, 2] or None, materials uint64[25, 2] or None) accumulated on the device so far."""
+        flags, _, shape = self.dose_info()
+        vox = np.zeros(shape + (2,), dtype=np.uint64) if flags & 2 else None
+        mat = np.zeros((25, 2), dtype=np.uint64) if flags & 1 else None
+        _check(self.lib.mcgpu_dose_read(self.h, vox.ctypes.data if vox is not None else None, mat.ctypes.data if mat is not None else None))
+        return vox, mat
+
+    def dose_clear(self):
+        _check(self.lib.mcgpu_dose_clear(self.h))
+
+    def write_dose_report(self, voxels, materials, histories_per_projection: int, seconds: float = 0.0) -> str:
+        """Writes the voxel dose files (when `voxels` is given) and returns the text of both reports."""
+        v = np.ascontiguousarray(voxels, dtype=np.uint64) if voxels is not None else None
+        m = np.ascontiguousarray(materials, dtype=np.uint64) if materials is not None else None
+        log = C.create_string_buffer(1 << 16)
+        _check(self.lib.mcgpu_write_dose_report(self.h, v.ctypes.data if v is not None else None, m.ctypes.data if m is not None else None,
+                                                int(histories_per_projection), float(seconds), log, len(log)))
+        return log.value.decode(errors="replace")
 
     def run_all(self, mode="fast", write_projections=True, histories: Optional[int] = None):
         """The projection loop of main() (MC-GPU_v1.3.cu:667-1056) on this context's GPU."""

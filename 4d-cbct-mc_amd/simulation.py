@@ -38,6 +38,9 @@ def create_mcgpu_input(
     gpu_ids: Sequence[int] = (0,),
     threads_per_block: int = DEFAULTS.threads_per_block,
     histories_per_thread: int = DEFAULTS.histories_per_thread,
+    tally_material_dose: bool = False,
+    tally_voxel_dose: bool = False,
+    dose_roi=((1, 1), (1, 1), (1, 1)),
 ) -> str:
     """Render an MC-GPU input file.  Lengths in mm (converted to cm like the reference)."""
     cm = lambda v: round(v / 10.0, 6)
@@ -78,12 +81,13 @@ def create_mcgpu_input(
     L.append("0.0  # VERTICAL TRANSLATION BETWEEN PROJECTIONS (HELICAL SCAN)")
     L.append("")
     L.append("#[SECTION DOSE DEPOSITION v.2012-12-12]")
-    L.append("NO  # TALLY MATERIAL DOSE? [YES/NO]")
-    L.append("NO  # TALLY 3D VOXEL DOSE? [YES/NO]")
+    # the reference template hard-codes NO/NO (mcgpu_input.jinja2:37-38); the engine implements both tallies
+    L.append(("YES" if tally_material_dose else "NO") + "  # TALLY MATERIAL DOSE? [YES/NO]")
+    L.append(("YES" if tally_voxel_dose else "NO") + "  # TALLY 3D VOXEL DOSE? [YES/NO]")
     L.append(f"{output_folder}/dose.dat  # OUTPUT VOXEL DOSE FILE NAME")
-    L.append("1 1  # Dose ROI X")
-    L.append("1 1  # Dose ROI Y")
-    L.append("1 1  # Dose ROI Z")
+    L.append(f"{dose_roi[0][0]} {dose_roi[0][1]}  # VOXEL DOSE ROI: X-index min max (first voxel has index 1)")
+    L.append(f"{dose_roi[1][0]} {dose_roi[1][1]}  # VOXEL DOSE ROI: Y-index min max")
+    L.append(f"{dose_roi[2][0]} {dose_roi[2][1]}  # VOXEL DOSE ROI: Z-index min max")
     L.append("")
     L.append("#[SECTION VOXELIZED GEOMETRY FILE v.2009-11-30]")
     L.append(f"{voxel_geometry_filepath}  # VOXELIZED GEOMETRY FILE")
@@ -116,7 +120,8 @@ class MCSimulation:
                  source_to_isocenter_distance=DEFAULTS.source_to_isocenter_distance,
                  random_seed=DEFAULTS.random_seed, source_polar_aperture=DEFAULTS.source_polar_aperture,
                  source_azimuthal_aperture=DEFAULTS.source_azimuthal_aperture,
-                 threads_per_block=DEFAULTS.threads_per_block, histories_per_thread=DEFAULTS.histories_per_thread):
+                 threads_per_block=DEFAULTS.threads_per_block, histories_per_thread=DEFAULTS.histories_per_thread,
+                 tally_material_dose=False, tally_voxel_dose=False, dose_roi=((1, 1), (1, 1), (1, 1))):
         self.geometry = geometry
         self.material_filepaths = list(material_filepaths)
         self.xray_spectrum_filepath = xray_spectrum_filepath
@@ -134,6 +139,9 @@ class MCSimulation:
         self.source_azimuthal_aperture = source_azimuthal_aperture
         self.threads_per_block = threads_per_block
         self.histories_per_thread = histories_per_thread
+        self.tally_material_dose = tally_material_dose
+        self.tally_voxel_dose = tally_voxel_dose
+        self.dose_roi = dose_roi
 
     def prepare_simulation(self, output_folder, geometry_output_folder=None, output_suffix="", gpu_ids=(0,),
                            force_geometry_recompile=False, compress_geometry=True, engine=None) -> Path:
@@ -157,7 +165,8 @@ class MCSimulation:
             source_azimuthal_aperture=self.source_azimuthal_aperture, n_detector_pixels=self.n_detector_pixels,
             detector_size=self.detector_size, source_to_detector_distance=self.source_to_detector_distance,
             source_to_isocenter_distance=self.source_to_isocenter_distance, random_seed=self.random_seed,
-            gpu_ids=gpu_ids, threads_per_block=self.threads_per_block, histories_per_thread=self.histories_per_thread)
+            gpu_ids=gpu_ids, threads_per_block=self.threads_per_block, histories_per_thread=self.histories_per_thread,
+            tally_material_dose=self.tally_material_dose, tally_voxel_dose=self.tally_voxel_dose, dose_roi=self.dose_roi)
         input_filepath.write_text(text)
         return input_filepath
 

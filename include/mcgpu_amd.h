@@ -108,6 +108,20 @@ int mcgpu_run_projection(mcgpu_ctx *ctx, int p, int mode, int seed, unsigned lon
 int mcgpu_write_projection(mcgpu_ctx *ctx, int p, const uint64_t *image_host, unsigned long long total_histories, double seconds,
                            const char *file_name);
 
+/* Dose tallies (tally_materials_dose MC-GPU_kernel_v1.3.cu:1547-1563, tally_voxel_energy_deposition :418-443; enabled by
+ * SECTION DOSE DEPOSITION of the input file, MC-GPU_v1.3.cu:1619-1709).  The context owns device buffers that every
+ * launch adds into (all projections accumulate, as in the reference).
+ *   flags: bit 0 = material dose tally, bit 1 = voxel dose tally; roi6 = 0-based inclusive xmin,xmax,ymin,ymax,zmin,zmax;
+ *   voxels: uint64 pairs {Edep*100, Edep^2} per ROI voxel (x fastest); materials: uint64 pairs x 25 material numbers. */
+int mcgpu_dose_info(const mcgpu_ctx *ctx, int *flags, int roi6[6], size_t *roi_voxels);
+int mcgpu_dose_read(mcgpu_ctx *ctx, uint64_t *voxels_out /* 2*roi_voxels or NULL */, uint64_t *materials_out /* 50 or NULL */);
+int mcgpu_dose_clear(mcgpu_ctx *ctx);
+/* report_voxels_dose (MC-GPU_v1.3.cu:2976-3199: ASCII z-plane file + <file>.raw + <file>_2sigma.raw) when `voxels` is
+ * given, report_materials_dose (:3214-3262) when `materials` is given.  The text the reference prints to stdout goes to
+ * `log` (NUL-terminated, truncated to log_bytes) or, when log is NULL, to stdout. */
+int mcgpu_write_dose_report(mcgpu_ctx *ctx, const uint64_t *voxels, const uint64_t *materials, unsigned long long histories_per_projection,
+                            double seconds, char *log, size_t log_bytes);
+
 /* Voxel geometry writer (cbctmc/mc/voxel_data.pyx:12-72 + mcgpu_geometry.jinja2 header fields):
  * material/density are [z][y][x] contiguous, spacing in cm. */
 int mcgpu_write_voxel_file(const char *path, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density,

@@ -34,8 +34,27 @@ import cases  # noqa: E402
 import oracle_lib as ol  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
-NBATCH = {"air": 200, "water": 200, "catphan64": 400, "catphan64_ct": 100, "slab_angles": 100}
+NBATCH = {"air": 200, "water": 200, "catphan64": 400, "catphan64_ct": 100, "slab_angles": 100, "catphan64_dose": 150}
 HPT = 150
+
+
+class capture:
+    """Redirect the process's stdout (C stdio included) into a file."""
+
+    def __init__(self, path):
+        self.path = str(path)
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.fd = os.open(self.path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.dup2(self.fd, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.fd)
+        os.close(self.saved)
 
 
 class quiet:
@@ -188,6 +207,36 @@ def case_fixture(ref, name, workdir):
         out["ascii_num_lines"] = len(lines)
         out["ascii_comment_tail"] = np.array([l for l in lines if l.startswith("#")][-5:])
     out["nbatch_hpt"] = np.array([nb, HPT])
+    # dose tallies (accumulated by the reference over the projections tracked above)
+    roi, ref_vox, ref_mat = ref.dose()
+    if roi[1] > -1 or int(ref.scalars["flag_material_dose"]) == 1:
+        out["dose_roi"] = np.array(roi)
+        out["dose_materials_ref"] = ref_mat
+        for mode, tag in ((ol.MATH_LIBM, "libm"), (ol.MATH_PORTABLE, "portable")):
+            vox, mat = T.enable_dose(roi if roi[1] > -1 else None, True)
+            for p in range(nproj):
+                T.track(p, 42 + 1000 * p, 0, nb, HPT, mode)
+            if tag == "libm":
+                assert np.array_equal(mat, ref_mat), f"oracle(libm) material dose != reference on {name}"
+                if roi[1] > -1:
+                    assert np.array_equal(vox.reshape(-1, 2), ref_vox), f"oracle(libm) voxel dose != reference on {name}"
+            else:
+                out["dose_materials_portable"] = mat.copy()
+            if roi[1] > -1:
+                i, v = sparse(vox.reshape(-1))
+                out[f"dose_voxels_{tag}_idx"], out[f"dose_voxels_{tag}_val"] = i, v
+                out["dose_voxels_shape"] = np.array(vox.shape)
+        T.ct.voxels_edep, T.ct.materials_dose = None, None
+        with tempfile.TemporaryDirectory() as rep:
+            with capture(rep + "/stdout.txt"):
+                ref.report_dose(rep + "/dose.dat", nb * HPT, 1.0)
+            out["dose_stdout_rows"] = np.array([l for l in open(rep + "/stdout.txt").read().split("\n") if l.startswith("\t")])
+            if roi[1] > -1:
+                lines = open(rep + "/dose.dat").read().split("\n")
+                sep = max(i for i, l in enumerate(lines) if l.startswith("# ====="))
+                out["dose_file_body"] = np.array(lines[sep + 1:])
+                out["dose_raw_sha256"] = np.array([hashlib.sha256(open(rep + "/dose.dat" + sfx, "rb").read()).hexdigest() for sfx in (".raw", "_2sigma.raw")])
+        print(f"   dose: ROI {roi}, material counters {int(ref_mat[:, 0].sum())}, voxel words {0 if ref_vox is None else int(np.count_nonzero(ref_vox))}")
     np.savez_compressed(GOLD / f"case_{name}.npz", **out)
     nz = sum(len(out[f"ref_idx_p{p}"]) for p in range(nproj))
     print(f"case {name}: {nproj} projection(s), {nb*HPT} histories each, {nz} non-zero tally words, files {names}")

@@ -493,6 +493,27 @@ static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state,
   }
 }
 
+/* tally_materials_dose (K.cu:1547-1563) + tally_voxel_energy_deposition (K.cu:418-443), CPU-build rounding */
+static void tally_dose(const oracle_tables *T, float Edep, int mat, const f3 *pos, int shared)
+{
+  if (T->materials_dose) {
+    tally_add(&T->materials_dose[2 * mat], (unsigned long long)(Edep * 100.0f + 0.5f), shared);
+    tally_add(&T->materials_dose[2 * mat + 1], (unsigned long long)(Edep * Edep + 0.5f), shared);
+  }
+  if (T->voxels_edep && T->dose_roi[1] > -1) {
+    const int *r = T->dose_roi;
+    const int x = (short)(int)(pos->x * T->inv_voxel_size[0]), y = (short)(int)(pos->y * T->inv_voxel_size[1]),
+              z = (short)(int)(pos->z * T->inv_voxel_size[2]);
+    if (x < r[0] || x > r[1] || y < r[2] || y > r[3] || z < r[4] || z > r[5]) return;
+    {
+      const int DX = 1 + (r[1] - r[0]);
+      const int v = (x - r[0]) + (y - r[2]) * DX + (z - r[4]) * DX * (1 + (r[3] - r[2]));
+      tally_add(&T->voxels_edep[2 * (size_t)v], (unsigned long long)(Edep * 100.0f + 0.5f), shared);
+      tally_add(&T->voxels_edep[2 * (size_t)v + 1], (unsigned long long)(Edep * Edep + 0.5f), shared);
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * track_particles (K.cu:120-384): one batch of `hpt` histories
  * ------------------------------------------------------------------------------------------ */
@@ -545,8 +566,10 @@ static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, i
       if (randno < prob) {
         double costh;
         C->compton++;
+        randno = energy;
         gcoa(T, &energy, &costh, mat, &seed, pm, &C->rng);
         rotate_dir(&dir, costh, 6.28318530717958647693 * ranecu_d(&seed, &C->rng), pm);
+        randno = energy - randno;  /* minus the energy lost (K.cu:299) */
         index = (int)((energy - T->e0) * T->ide + 0.00001f);
         if (index > -1) {
           mfpW = Wt[2 * index] + energy * Wt[2 * index + 1];
@@ -564,9 +587,11 @@ static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, i
           scatter_state = (scatter_state == 0) ? 2 : 3;
         } else {
           C->photo++;
+          randno = -energy;
           index = -11;
         }
       }
+      if (randno < -0.001f) tally_dose(T, -1.0f * randno, mat, &pos, shared);  /* K.cu:356-367 */
       if (index < 0) break;
     }
     if (index > -1) tally_image(energy, &pos, &dir, scatter_state, image, S, D, C, shared);

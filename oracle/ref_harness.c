@@ -44,6 +44,7 @@ static short int H_dose_ROI[6];
 static ulonglong2 *H_voxels_Edep = NULL;
 static int H_voxels_Edep_bytes = 0;
 static ulonglong2 H_materials_dose[MAX_MATERIALS];
+static double H_mass_materials[MAX_MATERIALS];
 static unsigned long long int H_total_histories;
 static int H_histories_per_thread, H_seed_input, H_num_threads_per_block, H_gpu_id, H_num_projections;
 static int H_flag_material_dose = -2, H_enable_specific_angles = -2;
@@ -123,6 +124,9 @@ const void *ref_get(const char *name, long *nbytes)
   if (!strcmp(name, "density_nominal"))  RET(H_density_nominal, sizeof(H_density_nominal));
   if (!strcmp(name, "image"))            RET(H_image, H_image_bytes);
   if (!strcmp(name, "materials_dose"))   RET(H_materials_dose, sizeof(H_materials_dose));
+  if (!strcmp(name, "voxels_edep"))      RET(H_voxels_Edep, H_voxels_Edep_bytes);
+  if (!strcmp(name, "dose_roi"))         RET(H_dose_ROI, sizeof(H_dose_ROI));
+  if (!strcmp(name, "mass_materials"))   RET(H_mass_materials, sizeof(H_mass_materials));
   if (!strcmp(name, "specific_angles"))  RET(H_specific_angles, sizeof(H_specific_angles));
 #undef RET
   *nbytes = -1;
@@ -142,8 +146,16 @@ void ref_get_scalars(double *out /* [16] */)
 void ref_clear_image(void)
 {
   int kk;
+  (void)kk;
   memset(H_image, 0, H_image_bytes);
+}
+
+/* Dose tallies accumulate over projections (MC-GPU_v1.3.cu:1062-1165); cleared on request only. */
+void ref_clear_dose(void)
+{
+  int kk;
   for (kk = 0; kk < MAX_MATERIALS; kk++) { H_materials_dose[kk].x = 0; H_materials_dose[kk].y = 0; }
+  if (H_voxels_Edep != NULL && H_dose_ROI[1] > -1) memset(H_voxels_Edep, 0, H_voxels_Edep_bytes);
 }
 
 /* The CPU history loop of main() (MC-GPU_v1.3.cu:953-958) for batches [batch0, batch0+nbatches). */
@@ -165,6 +177,25 @@ int ref_report(const char *out_base, int num_p, unsigned long long total_histori
   return report_image(base, H_detector_data, H_source_data, H_mean_energy_spectrum, H_image, seconds,
                       total_histories, num_p, H_num_projections, H_D_angle, H_initial_angle, 0, 1,
                       &H_enable_specific_angles, H_specific_angles);
+}
+
+/* report_voxels_dose (MC-GPU_v1.3.cu:2976) when the ROI is enabled, then report_materials_dose (:3214), on the
+ * current tallies; the material masses are computed as main() does (:579-585). */
+int ref_report_dose(const char *out_file, unsigned long long total_histories, double seconds)
+{
+  char name[250];
+  int kk;
+  double voxel_volume = 1.0 / ( ((double)H_voxel_data.inv_voxel_size.x) * ((double)H_voxel_data.inv_voxel_size.y) * ((double)H_voxel_data.inv_voxel_size.z) );
+  for (kk = 0; kk < MAX_MATERIALS; kk++) H_mass_materials[kk] = 0.0;
+  for (kk = 0; kk < (H_voxel_data.num_voxels.x * H_voxel_data.num_voxels.y * H_voxel_data.num_voxels.z); kk++)
+    H_mass_materials[((int)H_voxel_mat_dens[kk].x) - 1] += ((double)H_voxel_mat_dens[kk].y) * voxel_volume;
+  strncpy(name, out_file, 249); name[249] = '\0';
+  if (H_dose_ROI[1] > -1)
+    report_voxels_dose(name, H_num_projections, &H_voxel_data, H_voxel_mat_dens, H_voxels_Edep, seconds, total_histories,
+                       H_dose_ROI[0], H_dose_ROI[1], H_dose_ROI[2], H_dose_ROI[3], H_dose_ROI[4], H_dose_ROI[5], H_source_data);
+  report_materials_dose(H_num_projections, total_histories, H_density_nominal, H_materials_dose, H_mass_materials);
+  fflush(stdout);
+  return 0;
 }
 
 /* ---- known-answer entry points for the small device helpers ---- */

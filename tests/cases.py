@@ -65,6 +65,11 @@ CASES = {
     "catphan64": (_catphan_small, dict(n_projections=1, n_histories=300_000, **SMALL_DET)),
     "catphan64_ct": (_catphan_small, dict(n_projections=4, angle_between_projections=90.0, n_histories=60_000, **SMALL_DET)),
     "slab_angles": (_slab_nonsquare, dict(projection_angles=[270.0, 300.5, 45.25], n_histories=60_000, **SMALL_DET)),
+    # both dose tallies on (the reference template keeps them off): ROI in 1-based inclusive voxel indices; two
+    # projections, because the dose arrays accumulate over the scan
+    "catphan64_dose": (_catphan_small, dict(n_projections=2, angle_between_projections=90.0, n_histories=60_000,
+                                            tally_material_dose=True, tally_voxel_dose=True,
+                                            dose_roi=((9, 56), (5, 60), (17, 48)), **SMALL_DET)),
 }
 
 

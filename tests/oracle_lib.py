@@ -35,6 +35,7 @@ class OracleTables(C.Structure):
         ("fco", C.c_void_p), ("uico", C.c_void_p), ("fj0", C.c_void_p), ("noscco", C.c_void_p),
         ("num_bins_espc", C.c_int), ("espc", C.c_void_p), ("espc_cutoff", C.c_void_p), ("espc_alias", C.c_void_p),
         ("source_data", C.c_void_p), ("detector_data", C.c_void_p),
+        ("dose_roi", C.c_int * 6), ("voxels_edep", C.c_void_p), ("materials_dose", C.c_void_p),
     ]
 
 
@@ -98,7 +99,23 @@ class TableSet:
         t.inv_voxel_size = (C.c_float * 3)(*self.inv_voxel_size)
         t.size_bbox = (C.c_float * 3)(*self.size_bbox)
         t.num_values, t.e0, t.ide, t.num_bins_espc = self.num_values, float(self.e0), float(self.ide), self.num_bins_espc
+        t.dose_roi = (C.c_int * 6)(32500, -32500, 32500, -32500, 32500, -32500)
+        t.voxels_edep, t.materials_dose = None, None
         self.ct = t
+        self.dose_voxels = self.dose_materials = None
+
+    def enable_dose(self, roi6=None, materials=True):
+        """Attach zeroed dose tallies (0-based inclusive ROI, or None for no voxel tally); returns (voxels, materials)."""
+        if roi6 is not None:
+            r = [int(x) for x in roi6]
+            shape = (r[5] - r[4] + 1, r[3] - r[2] + 1, r[1] - r[0] + 1, 2)
+            self.dose_voxels = np.zeros(shape, dtype=np.uint64)
+            self.ct.dose_roi = (C.c_int * 6)(*r)
+            self.ct.voxels_edep = self.dose_voxels.ctypes.data
+        if materials:
+            self.dose_materials = np.zeros((MAXMAT, 2), dtype=np.uint64)
+            self.ct.materials_dose = self.dose_materials.ctypes.data
+        return self.dose_voxels, self.dose_materials
 
     @property
     def detector(self):
@@ -137,6 +154,7 @@ class Reference:
         lib.ref_gcoa.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.ref_graa.argtypes = [C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.ref_source.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_report_dose.argtypes = [C.c_char_p, C.c_ulonglong, C.c_double]
         self.lib = lib
         self.loaded = None
 
@@ -197,6 +215,16 @@ class Reference:
             self.lib.ref_clear_image()
         self.lib.ref_track(num_p, seed, batch0, nbatches, hpt)
         return self.get("image", "<u8")
+
+    def dose(self):
+        """(roi6, voxels uint64[n, 2] or None, materials uint64[25, 2]) tallied since the last clear."""
+        roi = self.get("dose_roi", "<i2").astype(int).tolist()
+        vox = self.get("voxels_edep", "<u8").reshape(-1, 2) if roi[1] > -1 else None
+        return roi, vox, self.get("materials_dose", "<u8").reshape(MAXMAT, 2)
+
+    def report_dose(self, out_file, total_histories, seconds=0.0):
+        """report_voxels_dose (when the ROI is enabled) + report_materials_dose of the reference; stdout not captured."""
+        return self.lib.ref_report_dose(str(out_file).encode(), int(total_histories), float(seconds))
 
 
 def reference_available():
