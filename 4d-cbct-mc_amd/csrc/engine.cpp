@@ -26,6 +26,7 @@ int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
+hipError_t launch_finalize(unsigned long long* image, int nx, int nz, int crop_nx, double norm, float* planes, int clear, hipStream_t stream);
 
 namespace {
 
@@ -434,6 +435,7 @@ using namespace mcgpu;
 extern "C" {
 
 int mcgpu_abi_version(void) { return 1; }
+void mcgpu_set_last_error_(const char* message) { (void)set_error(-1, message ? message : "unknown failure"); }  // for scan.cpp
 const char* mcgpu_last_error(void) { return g_last_error.c_str(); }
 
 int mcgpu_create(const char* input_path, int device_id, mcgpu_ctx** out) {
@@ -484,6 +486,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "volume_kind") *value = ctx->dev.vol_kind;
   else if (k == "volume_bytes_device") *value = (long long)ctx->dev.vol_bytes;
   else if (k == "num_cus") *value = ctx->dev.num_cus;
+  else if (k == "device_id") *value = ctx->has_device ? ctx->dev.device_id : -1;
   else if (k == "brick_shift") *value = ctx->dev.brick_shift;
   else if (k == "brick_count") *value = ctx->dev.brick_count;
   else if (k == "bricks_mixed") *value = ctx->dev.bricks_mixed;
@@ -508,6 +511,8 @@ int mcgpu_config_f64(const mcgpu_ctx* ctx, const char* key, double* value) {
   else if (k == "vertical_translation") *value = c.vertical_translation;
   else if (k == "mean_energy_spectrum") *value = ctx->host.spectrum.mean_energy;
   else if (k == "e0") *value = ctx->host.mat.e0;
+  else if (k == "pixel_size_x_mm") *value = 10.0 / (double)ctx->host.detector[0].inv_pixel_size_X;
+  else if (k == "pixel_size_z_mm") *value = 10.0 / (double)ctx->host.detector[0].inv_pixel_size_Z;
   else if (k == "ide") *value = ctx->host.mat.ide;
   else return set_error(-2, std::string("unknown float key: ") + key);
   return 0;
@@ -746,6 +751,72 @@ int mcgpu_write_dose_report(mcgpu_ctx* ctx, const uint64_t* voxels, const uint64
     fputs(text.c_str(), stdout);
     fflush(stdout);
   }
+  return 0;
+  ABI_END
+}
+
+int mcgpu_finalize_projection(mcgpu_ctx* ctx, void* image_dev, unsigned long long total_histories, int crop_nx, void* planes_dev, int clear_image,
+                              void* hip_stream) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && image_dev && planes_dev && total_histories > 0, -1, "!!ERROR!! mcgpu_finalize_projection: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  const DetectorPose& d0 = ctx->host.detector[0];
+  const int cx = (crop_nx > 0 && crop_nx < d0.nx) ? crop_nx : d0.nx;
+  const double SCALE = 1.0 / 100.0f;
+  const double norm = SCALE * d0.inv_pixel_size_X * d0.inv_pixel_size_Z / ((double)total_histories);  // MC-GPU_v1.3.cu:2860-2861
+  HIP_TRY(launch_finalize((unsigned long long*)image_dev, d0.nx, d0.nz, cx, norm, (float*)planes_dev, clear_image, (hipStream_t)hip_stream));
+  return 0;
+  ABI_END
+}
+
+int mcgpu_finalize_projection_host(const mcgpu_ctx* ctx, const uint64_t* image_host, unsigned long long total_histories, int crop_nx,
+                                   float* planes_host) {
+  ABI_BEGIN
+  require(ctx && image_host && planes_host && total_histories > 0, -1, "!!ERROR!! mcgpu_finalize_projection_host: bad argument");
+  finalize_projection_host(ctx->host, image_host, total_histories, crop_nx, planes_host);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_stack_create(const char* path, int nx, int ny, int nslices, double spacing_x, double spacing_y, mcgpu_stack** out) {
+  ABI_BEGIN
+  require(path && out && nx > 0 && ny > 0 && nslices > 0, -1, "!!ERROR!! mcgpu_stack_create: bad argument");
+  *out = reinterpret_cast<mcgpu_stack*>(mha_create(path, nx, ny, nslices, spacing_x, spacing_y));
+  return 0;
+  ABI_END
+}
+int mcgpu_stack_append(mcgpu_stack* stack, const float* plane) {
+  ABI_BEGIN
+  require(stack && plane, -1, "!!ERROR!! mcgpu_stack_append: null argument");
+  mha_append(reinterpret_cast<MhaStack*>(stack), plane);
+  return 0;
+  ABI_END
+}
+int mcgpu_stack_finish(mcgpu_stack* stack, int replace_zeros, float* replacement_value) {
+  ABI_BEGIN
+  require(stack != nullptr, -1, "!!ERROR!! mcgpu_stack_finish: null argument");
+  const float v = mha_finish(reinterpret_cast<MhaStack*>(stack), replace_zeros != 0);
+  if (replacement_value) *replacement_value = v;
+  return 0;
+  ABI_END
+}
+int mcgpu_stack_read(const char* path, int dims3[3], float* data, size_t capacity_elements) {
+  ABI_BEGIN
+  require(path && dims3, -1, "!!ERROR!! mcgpu_stack_read: null argument");
+  std::vector<float> v;
+  mha_read(path, dims3, v);
+  if (data) {
+    require(capacity_elements >= v.size(), -2, "!!ERROR!! mcgpu_stack_read: buffer too small");
+    memcpy(data, v.data(), v.size() * 4);
+  }
+  return 0;
+  ABI_END
+}
+int mcgpu_normalize_stack(const char* total_stack, const char* air_stack, double sigma_y, double sigma_x, const char* out_stack, double spacing_x,
+                          double spacing_y) {
+  ABI_BEGIN
+  require(total_stack && air_stack && out_stack, -1, "!!ERROR!! mcgpu_normalize_stack: null argument");
+  normalize_stack(total_stack, air_stack, sigma_y, sigma_x, out_stack, spacing_x, spacing_y);
   return 0;
   ABI_END
 }

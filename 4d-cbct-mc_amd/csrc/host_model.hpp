@@ -143,6 +143,18 @@ void write_voxel_dose_report(const HostModel& m, const uint64_t* voxels_edep, un
 void format_materials_dose_report(const HostModel& m, const uint64_t* materials_dose, unsigned long long histories_per_projection,
                                   const double* mass, std::string& log);
 
+// Projection post-processing and MetaImage stacks (postprocess.cpp)
+struct MhaStack;
+void finalize_projection_host(const HostModel& m, const uint64_t* image, unsigned long long total_histories, int crop_nx, float* planes,
+                              int n_threads = 0);
+MhaStack* mha_create(const std::string& path, int nx, int ny, int nslices, double sx, double sy);
+void mha_append(MhaStack* s, const float* plane);
+float mha_finish(MhaStack* s, bool replace_zeros);
+void mha_read(const std::string& path, int dims[3], std::vector<float>& data);
+void gaussian_filter_2d(float* img, int ny, int nx, double sigma_y, double sigma_x);
+void normalize_stack(const std::string& total_path, const std::string& air_path, double sigma_y, double sigma_x, const std::string& out_path,
+                     double sx, double sy);
+
 // Fast text/binary voxel writers (cbctmc/mc/voxel_data.pyx + mcgpu_geometry header fields)
 size_t write_voxel_file(const std::string& path, const int n[3], const float spacing_cm[3], const uint8_t* material,
                         const float* density, bool gzip);

@@ -26,8 +26,24 @@ ABI_SYMBOLS = (
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
+    "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_finish",
+    "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan",
     "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
 )
+
+
+class ScanOptions(C.Structure):
+    """mcgpu_scan_options (include/mcgpu_amd.h)."""
+    _fields_ = [("mode", C.c_int), ("first_projection", C.c_int), ("num_projections", C.c_int),
+                ("histories_per_projection", C.c_ulonglong), ("crop_nx", C.c_int), ("write_ascii", C.c_int), ("write_stacks", C.c_int),
+                ("output_folder", C.c_char_p), ("air_stack", C.c_char_p), ("air_sigma_y", C.c_double), ("air_sigma_x", C.c_double),
+                ("pixel_spacing_x", C.c_double), ("pixel_spacing_y", C.c_double)]
+
+
+class ScanReport(C.Structure):
+    """mcgpu_scan_report (include/mcgpu_amd.h)."""
+    _fields_ = [("projections", C.c_int), ("histories_per_projection", C.c_ulonglong), ("seconds_total", C.c_double),
+                ("seconds_kernels", C.c_double), ("seconds_after_last_kernel", C.c_double), ("zero_replacement", C.c_float * 3)]
 
 
 class EngineError(RuntimeError):
@@ -75,6 +91,14 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_dose_read.argtypes = [vp, vp, vp]
     lib.mcgpu_dose_clear.argtypes = [vp]
     lib.mcgpu_write_dose_report.argtypes = [vp, vp, vp, cull, C.c_double, cp, C.c_size_t]
+    lib.mcgpu_finalize_projection.argtypes = [vp, vp, cull, ci, vp, ci, vp]
+    lib.mcgpu_finalize_projection_host.argtypes = [vp, vp, cull, ci, vp]
+    lib.mcgpu_stack_create.argtypes = [cp, ci, ci, ci, C.c_double, C.c_double, C.POINTER(vp)]
+    lib.mcgpu_stack_append.argtypes = [vp, vp]
+    lib.mcgpu_stack_finish.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    lib.mcgpu_stack_read.argtypes = [cp, C.POINTER(ci), vp, C.c_size_t]
+    lib.mcgpu_normalize_stack.argtypes = [cp, cp, C.c_double, C.c_double, cp, C.c_double, C.c_double]
+    lib.mcgpu_run_scan.argtypes = [vp, C.POINTER(ScanOptions), C.POINTER(ScanReport)]
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
@@ -105,6 +129,44 @@ def write_voxel_file(path, n, spacing_cm, material_zyx: np.ndarray, density_zyx:
     assert m.size == d.size == int(n[0]) * int(n[1]) * int(n[2])
     _check(load_library().mcgpu_write_voxel_file(str(path).encode(), (C.c_int * 3)(*map(int, n)), (C.c_float * 3)(*map(float, spacing_cm)),
                                                  m.ctypes.data, d.ctypes.data, int(bool(gzip))))
+
+
+class StackWriter:
+    """MetaImage float32 stack written plane by plane (the reference's `projections_to_itk` + `sitk.WriteImage`)."""
+
+    def __init__(self, path, nx: int, ny: int, nslices: int, spacing=(0.776, 0.776)):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.mcgpu_stack_create(str(path).encode(), nx, ny, nslices, float(spacing[0]), float(spacing[1]), C.byref(h)))
+        self.h, self.shape = h, (ny, nx)
+
+    def append(self, plane: np.ndarray):
+        a = np.ascontiguousarray(plane, dtype=np.float32)
+        assert a.shape == self.shape
+        _check(self.lib.mcgpu_stack_append(self.h, a.ctypes.data))
+
+    def finish(self, replace_zeros: bool = True) -> float:
+        v = C.c_float()
+        h, self.h = self.h, None
+        _check(self.lib.mcgpu_stack_finish(h, int(replace_zeros), C.byref(v)))
+        return v.value
+
+
+def stack_read(path) -> np.ndarray:
+    """float32 [nslices, ny, nx] of a MetaImage stack written by this engine (or SimpleITK, uncompressed)."""
+    lib = load_library()
+    dims = (C.c_int * 3)()
+    _check(lib.mcgpu_stack_read(str(path).encode(), dims, None, 0))
+    out = np.zeros((dims[2], dims[1], dims[0]), dtype=np.float32)
+    _check(lib.mcgpu_stack_read(str(path).encode(), dims, out.ctypes.data, out.size))
+    return out
+
+
+def normalize_stack(total_stack, air_stack, out_stack, sigma=(10.0, 10.0), spacing=(0.776, 0.776)):
+    """log(gaussian_filter(air, sigma) / total) -> out_stack (cbctmc/mc/projection.py:96-115); sigma None/0 = no filter."""
+    sy, sx = (0.0, 0.0) if not sigma else (float(sigma[0]), float(sigma[1]))
+    _check(load_library().mcgpu_normalize_stack(str(total_stack).encode(), str(air_stack).encode(), sy, sx, str(out_stack).encode(),
+                                                float(spacing[0]), float(spacing[1])))
 
 
 class Context:
@@ -221,6 +283,37 @@ class Context:
         _check(self.lib.mcgpu_write_projection(self.h, p, img.ctypes.data, int(total_histories), float(seconds),
                                                file_name.encode() if file_name else None))
         return file_name or self.projection_file_name(p)
+
+    # -- post-processing (cbctmc/mc/projection.py) and the whole-scan pipeline
+    def finalize_host(self, image: np.ndarray, total_histories: int, crop_nx: int = 0) -> np.ndarray:
+        """float32 [3, Nz, crop] = (total, unscattered, scattered), z flipped -- what the reference's Python gets from the ASCII file."""
+        img = np.ascontiguousarray(image, dtype=np.uint64).reshape(-1)
+        nz, nx = self.detector_shape
+        cx = crop_nx if 0 < crop_nx < nx else nx
+        out = np.zeros((3, nz, cx), dtype=np.float32)
+        _check(self.lib.mcgpu_finalize_projection_host(self.h, img.ctypes.data, int(total_histories), int(crop_nx), out.ctypes.data))
+        return out
+
+    def finalize_device(self, image_dev_ptr: int, total_histories: int, planes_dev_ptr: int, crop_nx: int = 0, clear: bool = False, stream: int = 0):
+        _check(self.lib.mcgpu_finalize_projection(self.h, C.c_void_p(image_dev_ptr), int(total_histories), int(crop_nx), C.c_void_p(planes_dev_ptr),
+                                                  int(clear), C.c_void_p(stream)))
+
+    def run_scan(self, mode="fast", first_projection=0, num_projections=0, histories=0, crop_nx=0, write_ascii=False, write_stacks=True,
+                 output_folder=None, air_stack=None, air_sigma=(10.0, 10.0), pixel_spacing=(0.0, 0.0)) -> dict:
+        """The whole projection loop as a device/host pipeline (mcgpu_run_scan); returns the timing report."""
+        o = ScanOptions()
+        o.mode, o.first_projection, o.num_projections = _MODES[mode], int(first_projection), int(num_projections)
+        o.histories_per_projection, o.crop_nx = int(histories), int(crop_nx)
+        o.write_ascii, o.write_stacks = int(bool(write_ascii)), int(bool(write_stacks))
+        o.output_folder = str(output_folder).encode() if output_folder else None
+        o.air_stack = str(air_stack).encode() if air_stack else None
+        o.air_sigma_y, o.air_sigma_x = (float(air_sigma[0]), float(air_sigma[1])) if air_sigma else (0.0, 0.0)
+        o.pixel_spacing_x, o.pixel_spacing_y = float(pixel_spacing[0]), float(pixel_spacing[1])
+        r = ScanReport()
+        _check(self.lib.mcgpu_run_scan(self.h, C.byref(o), C.byref(r)))
+        return {"projections": r.projections, "histories_per_projection": r.histories_per_projection, "seconds_total": r.seconds_total,
+                "seconds_kernels": r.seconds_kernels, "seconds_after_last_kernel": r.seconds_after_last_kernel,
+                "zero_replacement": [float(v) for v in r.zero_replacement]}
 
     # -- dose tallies (SECTION DOSE DEPOSITION of the input file)
     def dose_info(self):

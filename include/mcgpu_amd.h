@@ -122,6 +122,50 @@ int mcgpu_dose_clear(mcgpu_ctx *ctx);
 int mcgpu_write_dose_report(mcgpu_ctx *ctx, const uint64_t *voxels, const uint64_t *materials, unsigned long long histories_per_projection,
                             double seconds, char *log, size_t log_bytes);
 
+/* ---- projection post-processing and RTK-ready stacks (cbctmc/mc/projection.py:36-169, simulation.py:235-277) ----
+ * The reference's Python reads every ASCII projection back (np.loadtxt -> float32), flips z, crops the half-fan columns
+ * and stacks {total, unscattered, scattered} into MetaImage files.  These entry points produce the same float32 numbers
+ * from the integer tallies directly.  planes = float[3][Nz][crop_nx] (total, unscattered, scattered); crop_nx <= 0 or
+ * >= Nx keeps the full width. */
+int mcgpu_finalize_projection(mcgpu_ctx *ctx, void *image_dev, unsigned long long total_histories, int crop_nx, void *planes_dev,
+                              int clear_image, void *hip_stream);
+int mcgpu_finalize_projection_host(const mcgpu_ctx *ctx, const uint64_t *image_host, unsigned long long total_histories, int crop_nx,
+                                   float *planes_host);
+/* MetaImage float32 stack written plane by plane (projections_to_itk, projection.py:118-166: spacing (sx, sy, 1), origin
+ * (-nx*sx/2, -ny*sy/2, 0)).  finish(replace_zeros != 0) applies np.where(stack == 0, stack[stack > 0].min(), stack). */
+typedef struct mcgpu_stack mcgpu_stack;
+int mcgpu_stack_create(const char *path, int nx, int ny, int nslices, double spacing_x, double spacing_y, mcgpu_stack **out);
+int mcgpu_stack_append(mcgpu_stack *stack, const float *plane);
+int mcgpu_stack_finish(mcgpu_stack *stack, int replace_zeros, float *replacement_value);
+int mcgpu_stack_read(const char *path, int dims3[3], float *data /* NULL: dims only */, size_t capacity_elements);
+/* normalize_projections (projection.py:96-115): out = log(gaussian_filter(air, (sigma_y, sigma_x)) / total), scipy's
+ * gaussian_filter semantics (truncate 4, reflect); sigma <= 0 skips the filter. */
+int mcgpu_normalize_stack(const char *total_stack, const char *air_stack, double sigma_y, double sigma_x, const char *out_stack,
+                          double spacing_x, double spacing_y);
+
+/* Whole-scan driver on the context's GPU: the projection loop of main() (MC-GPU_v1.3.cu:667-1056) as a pipeline --
+ * track -> finalize (+ clear) on the device, double-buffered pinned copies, a writer thread for the files -- so the GPU
+ * never waits for output.  Zero-initialise the struct; every field has a usable default. */
+typedef struct mcgpu_scan_options {
+  int mode;                                     /* MCGPU_MODE_FAST (default) or MCGPU_MODE_COMPAT */
+  int first_projection, num_projections;        /* num_projections 0 = all remaining */
+  unsigned long long histories_per_projection;  /* 0 = the input file's value */
+  int crop_nx;                                  /* half-fan crop of the stacks (reference default 1024); 0 = full width */
+  int write_ascii;                              /* the reference's per-projection ASCII files */
+  int write_stacks;                             /* projections_{total,unscattered,scattered}.mha in output_folder */
+  const char *output_folder;                    /* NULL = folder of the input file's output base name */
+  const char *air_stack;                        /* air scan's projections_total.mha: also write projections_total_normalized.mha */
+  double air_sigma_y, air_sigma_x;              /* gaussian denoising of the air projection (reference default 10, 10) */
+  double pixel_spacing_x, pixel_spacing_y;      /* MetaImage spacing [mm]; 0 = detector pixel size of the input file */
+} mcgpu_scan_options;
+typedef struct mcgpu_scan_report {
+  int projections;
+  unsigned long long histories_per_projection;
+  double seconds_total, seconds_kernels, seconds_after_last_kernel;
+  float zero_replacement[3];
+} mcgpu_scan_report;
+int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
+
 /* Voxel geometry writer (cbctmc/mc/voxel_data.pyx:12-72 + mcgpu_geometry.jinja2 header fields):
  * material/density are [z][y][x] contiguous, spacing in cm. */
 int mcgpu_write_voxel_file(const char *path, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density,
