@@ -6,7 +6,12 @@
 //   --mode fast|compat   kernel personality (default fast)
 //   --gpus N             history-shard every projection over N devices of this node (default 1);
 //                        per-device tallies are summed on the host (integers: order-independent)
-//   --no-output          skip the ASCII projection files (timing runs)
+//   --no-output          skip the ASCII projection files (timing runs, or stacks only)
+//   --stacks             also write projections_{total,unscattered,scattered}.mha next to the projection files
+//                        (what cbctmc/mc/simulation.py:235-277 builds from the ASCII files afterwards)
+//   --crop N             half-fan crop of the stacks (default 1024 when the detector has 1848 columns, else none)
+//   --air FILE           air scan's projections_total.mha: also write projections_total_normalized.mha
+// One GPU runs the pipelined scan driver (mcgpu_run_scan); several GPUs use the per-projection loop below.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,8 +32,13 @@ int main(int argc, char** argv) {
     return 255;
   }
   int mode = MCGPU_MODE_FAST, ngpu = 1;
-  bool write_out = true;
+  bool write_out = true, stacks = false;
+  int crop = -1;
+  const char* air = nullptr;
   for (int i = 2; i < argc; ++i) {
+    if (!strcmp(argv[i], "--stacks")) { stacks = true; continue; }
+    if (!strcmp(argv[i], "--crop") && i + 1 < argc) { crop = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--air") && i + 1 < argc) { air = argv[++i]; continue; }
     if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = !strcmp(argv[++i], "compat") ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--no-output")) write_out = false;
@@ -67,14 +77,57 @@ int main(int argc, char** argv) {
   printf("\n    -- INITIALIZATION finished: elapsed time = %.3f s. \n\n\n    -- MONTE CARLO LOOP phase.\n\n", now_s() - t_begin);
   fflush(stdout);
 
+  long long det_nx = 0, det_nz = 0;
+  mcgpu_config_i64(ctx[0], "num_pixels_x", &det_nx);
+  mcgpu_config_i64(ctx[0], "num_pixels_z", &det_nz);
+  if (crop < 0) crop = det_nx == 1848 ? 1024 : 0;  // cbctmc/defaults.py:61-64
+  const int crop_nx = (crop > 0 && crop < det_nx) ? crop : (int)det_nx;
   int blocks = 1, hpt_eff = (int)hpt;
   unsigned long long total = (unsigned long long)hist;
   if (mode == MCGPU_MODE_COMPAT) mcgpu_launch_shape((unsigned long long)hist, (int)tpb, (int)hpt, &blocks, &hpt_eff, &total);
-  std::vector<std::vector<uint64_t>> img(ngpu, std::vector<uint64_t>(words));
   double t_mc = 0.0;
+  if (ngpu == 1) {
+    mcgpu_scan_options so;
+    memset(&so, 0, sizeof so);
+    so.mode = mode;
+    so.crop_nx = crop_nx;
+    so.write_ascii = write_out ? 1 : 0;
+    so.write_stacks = stacks ? 1 : 0;
+    so.air_stack = air;
+    so.air_sigma_y = so.air_sigma_x = 10.0;
+    so.pixel_spacing_x = so.pixel_spacing_y = 0.776;  // cbctmc/mc/projection.py:73
+    mcgpu_scan_report sr;
+    memset(&sr, 0, sizeof sr);
+    if (mcgpu_run_scan(ctx[0], &so, &sr) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 253; }
+    t_mc = sr.seconds_kernels;
+    total = sr.histories_per_projection;
+    printf("          *** SCAN PERFORMANCE REPORT ***\n              Projections:         %d\n              Simulated x rays:    %llu per projection\n"
+           "              Kernel time [s]:     %.3f\n              Scan time [s]:       %.3f (output overlapped; %.3f s after the last kernel)\n"
+           "              Speed [x-rays/s]:    %.2f\n\n",
+           sr.projections, total, sr.seconds_kernels, sr.seconds_total, sr.seconds_after_last_kernel,
+           sr.seconds_total > 0 ? (double)total * sr.projections / sr.seconds_total : 0.0);
+  }
+  std::vector<std::vector<uint64_t>> img(ngpu, std::vector<uint64_t>(ngpu > 1 ? words : 0));
+  mcgpu_stack* stk[3] = {nullptr, nullptr, nullptr};
+  std::vector<float> planes;
+  std::string out_folder;
+  if (ngpu > 1 && stacks) {
+    char name[1024];
+    mcgpu_projection_file_name(ctx[0], 0, name, sizeof name);
+    out_folder = name;
+    const size_t slash = out_folder.find_last_of('/');
+    out_folder = slash == std::string::npos ? "." : out_folder.substr(0, slash);
+    static const char* kNames[3] = {"projections_total.mha", "projections_unscattered.mha", "projections_scattered.mha"};
+    for (int k = 0; k < 3; ++k)
+      if (mcgpu_stack_create((out_folder + "/" + kNames[k]).c_str(), crop_nx, (int)det_nz, (int)nproj, 0.776, 0.776, &stk[k]) != 0) {
+        printf("\n\n   %s\n\n", mcgpu_last_error());
+        return 253;
+      }
+    planes.resize((size_t)3 * crop_nx * det_nz);
+  }
   int cur_seed = (int)seed;
   const double RAD2DEG = 180.0 / 3.14159265358979323846;
-  for (int p = 0; p < (int)nproj; ++p) {
+  for (int p = 0; p < (int)nproj && ngpu > 1; ++p) {
     const double ang = a0 + p * d_angle;
     if (nproj != 1 && (ang < roi0 || ang > roi1)) {
       printf("         << Skipping projection #%d of %d >> Angle %f degrees: outside angular region of interest.\n", p + 1, (int)nproj, ang * RAD2DEG);
@@ -107,9 +160,23 @@ int main(int argc, char** argv) {
       printf("\n\n   %s\n\n", mcgpu_last_error());
       return 253;
     }
+    if (stk[0]) {
+      int src = mcgpu_finalize_projection_host(ctx[0], img[0].data(), total, crop_nx, planes.data());
+      for (int k = 0; k < 3 && src == 0; ++k) src = mcgpu_stack_append(stk[k], planes.data() + (size_t)k * crop_nx * det_nz);
+      if (src != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 253; }
+    }
     // next projection gets a disjoint stream set (update_seed_PRNG, MC-GPU_v1.3.cu:869)
     if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
     fflush(stdout);
+  }
+  if (stk[0]) {
+    for (int k = 0; k < 3; ++k)
+      if (mcgpu_stack_finish(stk[k], 1, nullptr) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 253; }
+    if (air && mcgpu_normalize_stack((out_folder + "/projections_total.mha").c_str(), air, 10.0, 10.0,
+                                     (out_folder + "/projections_total_normalized.mha").c_str(), 0.776, 0.776) != 0) {
+      printf("\n\n   %s\n\n", mcgpu_last_error());
+      return 253;
+    }
   }
   // dose tallies accumulate over all projections (MC-GPU_v1.3.cu:1062-1165): sum the devices, report once
   int dose_flags = 0;

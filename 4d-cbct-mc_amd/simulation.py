@@ -170,12 +170,82 @@ class MCSimulation:
         input_filepath.write_text(text)
         return input_filepath
 
-    def run_simulation(self, output_folder, engine, gpu_ids=(0,), mode="fast", write_projections=True, **prepare_kwargs):
-        """Prepare inputs and run every projection on the GPU engine; returns the list of output files."""
-        input_filepath = self.prepare_simulation(output_folder, gpu_ids=gpu_ids, engine=engine, **prepare_kwargs)
+    _AIR_SIMULATION_FOLDER = "air"  # sim.py:38
+    STACK_PIXEL_SPACING = (0.776, 0.776)  # the spacing the reference stamps on its stacks (projection.py:73)
+
+    @staticmethod
+    def run_air_simulation(output_folder, engine, material_filepaths, xray_spectrum_filepath, n_histories=int(5e10), gpu_ids=(0,),
+                           mode="fast", **sim_kwargs):
+        """One air projection for the Beer-Lambert normalisation (sim.py:72-87): a 1-voxel air geometry, 5e10 histories."""
+        from .geometry import MCAirGeometry
+        folder = Path(output_folder) / MCSimulation._AIR_SIMULATION_FOLDER
+        sim = MCSimulation(MCAirGeometry(), material_filepaths, xray_spectrum_filepath, n_histories=n_histories, n_projections=1, **sim_kwargs)
+        return sim.run_simulation(folder, engine, gpu_ids=gpu_ids, mode=mode, run_air_simulation=False)
+
+    @staticmethod
+    def _already_simulated(output_folder) -> bool:
+        return (Path(output_folder) / "projections_total.mha").is_file()  # sim.py:89-93
+
+    def run_simulation(self, output_folder, engine, gpu_ids=(0,), mode="fast", run_air_simulation=False,
+                       air_projection_denoise_kernel_size=(10, 10), clean=True, stack_projections=True, force_rerun=False,
+                       air_n_histories=int(5e10), **prepare_kwargs):
+        """`BaseMCSimulation.run_simulation` (sim.py:370-427) on the in-process engine: the docker/mpirun launch and the
+        ASCII -> numpy -> SimpleITK post-processing are replaced by the engine's scan pipeline, which writes
+        projections_{total,unscattered,scattered}.mha (and projections_total_normalized.mha with an air scan) directly.
+        `clean=False` additionally keeps the reference's per-projection ASCII files.  Returns the scan report."""
+        output_folder = Path(output_folder)
+        if self._already_simulated(output_folder) and not force_rerun:
+            return None
+        if run_air_simulation and not stack_projections:
+            raise ValueError("Cannot perform air normalization without stacking projections")  # sim.py:244-247
         gpu_ids = (gpu_ids,) if isinstance(gpu_ids, int) else tuple(gpu_ids)
+        air_stack = None
+        if run_air_simulation:
+            kw = dict(n_detector_pixels=self.n_detector_pixels, detector_size=self.detector_size,
+                      source_to_detector_distance=self.source_to_detector_distance,
+                      source_to_isocenter_distance=self.source_to_isocenter_distance, random_seed=self.random_seed,
+                      source_polar_aperture=self.source_polar_aperture, source_azimuthal_aperture=self.source_azimuthal_aperture)
+            self.run_air_simulation(output_folder, engine, self.material_filepaths, self.xray_spectrum_filepath, n_histories=air_n_histories,
+                                    gpu_ids=gpu_ids, mode=mode, **kw)
+            air_stack = output_folder / self._AIR_SIMULATION_FOLDER / "projections_total.mha"
+        input_filepath = self.prepare_simulation(output_folder, gpu_ids=gpu_ids, engine=engine, **prepare_kwargs)
+        half_fan = DEFAULTS.n_detector_pixels_half_fan[0] if tuple(self.n_detector_pixels) == tuple(DEFAULTS.n_detector_pixels) else 0
         ctx = engine.create(str(input_filepath), device=gpu_ids[0])
         try:
-            return ctx.run_all(mode=mode, write_projections=write_projections)
+            return ctx.run_scan(mode=mode, crop_nx=half_fan, write_ascii=not clean, write_stacks=stack_projections,
+                                output_folder=output_folder, air_stack=air_stack, air_sigma=air_projection_denoise_kernel_size,
+                                pixel_spacing=self.STACK_PIXEL_SPACING)
         finally:
             ctx.close()
+
+    @staticmethod
+    def postprocess_simulation(folder, engine, n_detector_pixels=DEFAULTS.n_detector_pixels,
+                               n_detector_pixels_half_fan=DEFAULTS.n_detector_pixels_half_fan, clean=True, stack_projections=True,
+                               air_normalization=True, air_projection_denoise_kernel_size=(10, 10)):
+        """`postprocess_simulation` (sim.py:235-277) for a folder of ASCII projection files written by the drop-in
+        executable: stacks them (same float32 values, MetaImage writer of the engine) and cleans up."""
+        import numpy as np
+        folder = Path(folder)
+        if air_normalization and not stack_projections:
+            raise ValueError("Cannot perform air normalization without stacking projections")
+        files = sorted(f for f in folder.iterdir() if PROJECTION_FILE_PATTERN.match(f.name))
+        if files and stack_projections:
+            nx, nz = n_detector_pixels
+            cx = n_detector_pixels_half_fan[0] if n_detector_pixels_half_fan else nx
+            writers = [engine.StackWriter(folder / f"projections_{m}.mha", cx, nz, len(files), MCSimulation.STACK_PIXEL_SPACING)
+                       for m in ("total", "unscattered", "scattered")]
+            for f in files:
+                data = np.loadtxt(f, dtype=np.float64).astype(np.float32).reshape(nz, nx, 4)  # projection.py:42-51
+                data = np.flip(data, axis=0)[:, :cx]
+                writers[0].append(data.sum(axis=-1))
+                writers[1].append(data[..., 0])
+                writers[2].append(data[..., 1:].sum(axis=-1))
+            for w in writers:
+                w.finish(replace_zeros=True)
+            if air_normalization:
+                engine.normalize_stack(folder / "projections_total.mha", folder / MCSimulation._AIR_SIMULATION_FOLDER / "projections_total.mha",
+                                       folder / "projections_total_normalized.mha", sigma=air_projection_denoise_kernel_size,
+                                       spacing=MCSimulation.STACK_PIXEL_SPACING)
+        if clean:
+            for f in files:
+                f.unlink()

@@ -54,18 +54,29 @@ def test_executable_reports_errors_like_the_reference(engine, tmp_path):
 
 
 def test_mcsimulation_mirror_runs_air_and_object_scans(engine, tmp_path):
-    """MCSimulation.run_simulation flow (sim.py:370-427): air scan + object scan -> log(air/object) is a sane attenuation image."""
+    """MCSimulation.run_simulation flow (sim.py:370-427): air scan + object scan + post-processing -> RTK-ready stacks;
+    log(air/object) is a sane attenuation image."""
     mats, spc = cases.material_files(), cases.spectrum_file()
     kw = dict(n_projections=1, n_detector_pixels=(231, 96), detector_size=(717.024, 297.984))
-    air = cases.simulation.MCSimulation(cases.geometry.MCAirGeometry(), mats, spc, n_histories=4_000_000, **kw)
     obj = cases.simulation.MCSimulation(cases.geometry.MCBoxGeometry(shape=(20, 20, 20), image_spacing=(10.0, 10.0, 10.0)), mats, spc,
                                         n_histories=4_000_000, **kw)
-    (name_a, img_a, _, n_a), = air.run_simulation(tmp_path / "air", engine, mode="fast")
-    (name_o, img_o, _, n_o), = obj.run_simulation(tmp_path / "obj", engine, mode="fast")
-    assert n_a == n_o == 4_000_000
-    nz, nx = img_a.shape[1:]
-    a = _read_like_reference(name_a, nz, nx).sum(axis=-1)
+    rep = obj.run_simulation(tmp_path / "obj", engine, mode="fast", run_air_simulation=True, air_n_histories=4_000_000, clean=False,
+                             air_projection_denoise_kernel_size=None)
+    assert rep["projections"] == 1 and rep["histories_per_projection"] == 4_000_000
+    assert obj.run_simulation(tmp_path / "obj", engine) is None, "an output folder with stacks counts as simulated (sim.py:389-395)"
+    nz, nx = 96, 231
+    eng = engine
+    # the stacks hold what the reference's Python reads from the ASCII files (kept because clean=False)
+    (name_o,) = [f for f in (tmp_path / "obj").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name)]
+    assert not [f for f in (tmp_path / "obj" / "air").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name)], \
+        "the air scan runs with clean=True like the reference's (sim.py:85-87)"
     o = _read_like_reference(name_o, nz, nx).sum(axis=-1)
+    o_stack = eng.stack_read(tmp_path / "obj" / "projections_total.mha")[0]
+    a_stack = eng.stack_read(tmp_path / "obj" / "air" / "projections_total.mha")[0]
+    a = a_stack
+    assert np.array_equal(o_stack, np.where(o == 0, o[o > 0].min(), o))
+    norm = eng.stack_read(tmp_path / "obj" / "projections_total_normalized.mha")[0]
+    assert np.allclose(norm, np.log(a_stack / o_stack), rtol=3e-7, atol=3e-7)
     # the same two scans on the CPU oracle (fewer histories), read through the same normalisation
     def oracle_total(sim_dir, n_batches=10000, hpt=150):
         with engine.create(sim_dir / "input.in", device=-1) as ctx:
@@ -74,7 +85,7 @@ def test_mcsimulation_mirror_runs_air_and_object_scans(engine, tmp_path):
             img, _ = T.track(0, 42, 0, n_batches, hpt, ol.MATH_LIBM, n_threads=16)
             norm = 0.01 * float(det[19]) * float(det[20]) / (n_batches * hpt)
             return np.flip(img.reshape(4, nz, nx).sum(axis=0).astype(np.float64) * norm, axis=0)
-    a_ref, o_ref = oracle_total(tmp_path / "air"), oracle_total(tmp_path / "obj")
+    a_ref, o_ref = oracle_total(tmp_path / "obj" / "air"), oracle_total(tmp_path / "obj")
     # masks from the (22x better sampled) GPU images, block-averaged 8x7 so that selection is not noise-driven
     blk = lambda im: im[: nz // 8 * 8, : nx // 7 * 7].reshape(nz // 8, 8, nx // 7, 7).mean(axis=(1, 3))
     ab, ob, abr, obr = blk(a), blk(o), blk(a_ref), blk(o_ref)
