@@ -26,6 +26,8 @@ int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
+hipError_t launch_warp(int nx, int ny, int nz, const unsigned char* mat, const float* dens, const float* dvf, unsigned char default_mat,
+                       float default_dens, unsigned char* out_mat, float* out_dens, hipStream_t stream);
 hipError_t launch_finalize(unsigned long long* image, int nx, int nz, int crop_nx, double norm, float* planes, int clear, hipStream_t stream);
 
 namespace {
@@ -821,11 +823,133 @@ int mcgpu_normalize_stack(const char* total_stack, const char* air_stack, double
   ABI_END
 }
 
+int mcgpu_stack_write_slice(mcgpu_stack* stack, int slice, const float* plane) {
+  ABI_BEGIN
+  require(stack && plane, -1, "!!ERROR!! mcgpu_stack_write_slice: null argument");
+  mha_write_slice(reinterpret_cast<MhaStack*>(stack), slice, plane);
+  return 0;
+  ABI_END
+}
+
+// ---- 4-D support: one resident context, many (geometry, projection angle) jobs (cbctmc/mc/simulation.py:527-710)
+int mcgpu_set_projection_angles(mcgpu_ctx* ctx, int n, const float* angles_deg) {
+  ABI_BEGIN
+  require(ctx && angles_deg && n >= 2 && n <= kMaxProjections, -1, "!!ERROR!! mcgpu_set_projection_angles: need 2..1024 angles");
+  HostModel& H = ctx->host;
+  require(H.cfg.num_projections >= 2, -2,
+          "!!ERROR!! mcgpu_set_projection_angles: the input file must define a CT trajectory (more than one projection)");
+  H.cfg.enable_specific_angles = 1;
+  H.cfg.specific_angles.assign(angles_deg, angles_deg + n);
+  H.cfg.num_projections = n;
+  H.source.resize(1);    // pose 0 is the input file's (MC-GPU_v1.3.cu:3313); the others follow the angles
+  H.detector.resize(1);
+  build_ct_trajectory(H);
+  if (ctx->has_device) {
+    DeviceModel& D = ctx->dev;
+    HIP_TRY(hipSetDevice(D.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    D.src_all = D.put(H.source);  // the old arrays stay allocated until the context is destroyed (180 B per projection)
+    D.det_all = D.put(H.detector);
+  }
+  return 0;
+  ABI_END
+}
+
+int mcgpu_set_geometry_arrays(mcgpu_ctx* ctx, const int n[3], const float spacing_cm[3], const uint8_t* material, const float* density) {
+  ABI_BEGIN
+  require(ctx && n && spacing_cm && material && density && n[0] > 0 && n[1] > 0 && n[2] > 0, -1, "!!ERROR!! mcgpu_set_geometry_arrays: bad argument");
+  HostModel& H = ctx->host;
+  VoxelGrid v;
+  for (int k = 0; k < 3; ++k) {
+    v.n[k] = n[k];
+    v.voxel_size[k] = spacing_cm[k];
+    v.size_bbox[k] = v.n[k] * v.voxel_size[k];
+    v.inv_voxel_size[k] = 1.0f / v.voxel_size[k];
+  }
+  const size_t nvox = v.count();
+  v.material.assign(material, material + nvox);
+  v.density.resize(nvox);
+  for (int k = 0; k < kMaxMaterials; ++k) v.density_max[k] = -999.0f;
+  // densities as the voxel file would carry them ("%.6f", cbctmc/mc/voxel_data.pyx:25), so that handing arrays over
+  // in-process gives the tables -- and therefore the tallies -- of the file-based flow
+  std::unordered_map<uint32_t, float> q;
+  for (size_t i = 0; i < nvox; ++i) {
+    uint32_t b;
+    memcpy(&b, &density[i], 4);
+    auto it = q.find(b);
+    float d;
+    if (it != q.end()) d = it->second;
+    else {
+      char t[64];
+      snprintf(t, sizeof t, "%.6f", (double)density[i]);
+      d = strtof(t, nullptr);
+      q.emplace(b, d);
+    }
+    const int mat = material[i];
+    require(mat >= 1 && mat <= kMaxMaterials, -2, "!!ERROR load_voxels!! Voxel material number out of range!!");
+    require(d >= 1.0e-9f, -2, "!!ERROR load_voxels!! Voxel density can not be 0 or negative");
+    v.density[i] = d;
+    if (d > v.density_max[mat - 1]) v.density_max[mat - 1] = d;
+  }
+  H.voxels = std::move(v);
+  if (H.cfg.dose_roi[1] > -1)
+    for (int ax = 0; ax < 3; ++ax) H.cfg.dose_roi[2 * ax + 1] = std::min(H.cfg.dose_roi[2 * ax + 1], H.voxels.n[ax] - 1);
+  // the Woodcock majorant and the set of loaded materials depend on the volume (MC-GPU_v1.3.cu:2220-2233,2294-2296)
+  H.mat = MaterialTables();
+  load_material_files(H.cfg.file_materials, H.voxels, H.mat);
+  ctx->table_cache.clear();
+  if (ctx->has_device) {
+    const int dev = ctx->dev.device_id;
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipDeviceSynchronize());
+    ctx->dev.release();
+    ctx->dev = DeviceModel();
+    upload_model(*ctx, dev);
+  }
+  return 0;
+  ABI_END
+}
+
+int mcgpu_warp_volume(mcgpu_ctx* ctx, const int n[3], const uint8_t* material, const float* density, const float* displacement,
+                      int default_material, float default_density, uint8_t* material_out, float* density_out) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && n && material && density && displacement && material_out && density_out, -1,
+          "!!ERROR!! mcgpu_warp_volume: bad argument (the context needs a device)");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  const size_t nvox = (size_t)n[0] * n[1] * n[2];
+  unsigned char *m_in = nullptr, *m_out = nullptr;
+  float *d_in = nullptr, *d_out = nullptr, *u = nullptr;
+  hipError_t err = hipSuccess;
+  auto step = [&](hipError_t e) { if (err == hipSuccess) err = e; };
+  step(hipMalloc((void**)&m_in, nvox)); step(hipMalloc((void**)&m_out, nvox));
+  step(hipMalloc((void**)&d_in, nvox * 4)); step(hipMalloc((void**)&d_out, nvox * 4)); step(hipMalloc((void**)&u, nvox * 12));
+  if (err == hipSuccess) {
+    step(hipMemcpy(m_in, material, nvox, hipMemcpyHostToDevice));
+    step(hipMemcpy(d_in, density, nvox * 4, hipMemcpyHostToDevice));
+    step(hipMemcpy(u, displacement, nvox * 12, hipMemcpyHostToDevice));
+    if (err == hipSuccess) step(launch_warp(n[0], n[1], n[2], m_in, d_in, u, (unsigned char)default_material, default_density, m_out, d_out, nullptr));
+    step(hipMemcpy(material_out, m_out, nvox, hipMemcpyDeviceToHost));
+    step(hipMemcpy(density_out, d_out, nvox * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(m_in); (void)hipFree(m_out); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(u);
+  HIP_TRY(err);
+  return 0;
+  ABI_END
+}
+
 int mcgpu_write_voxel_file(const char* path, const int n[3], const float spacing_cm[3], const uint8_t* material, const float* density,
                            int gzip) {
   ABI_BEGIN
   require(path && n && spacing_cm && material && density, -1, "!!ERROR!! mcgpu_write_voxel_file: null argument");
   write_voxel_file(path, n, spacing_cm, material, density, gzip != 0);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_write_voxel_binary(const char* path, const int n[3], const float spacing_cm[3], const uint8_t* material, const float* density) {
+  ABI_BEGIN
+  require(path && n && spacing_cm && material && density, -1, "!!ERROR!! mcgpu_write_voxel_binary: null argument");
+  write_voxel_binary(path, n, spacing_cm, material, density);
   return 0;
   ABI_END
 }

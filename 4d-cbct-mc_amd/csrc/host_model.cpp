@@ -5,6 +5,7 @@
 // from the same files.  Reference citations are docker/mcgpu/MC-GPU_v1.3.cu:<line>.
 #include "host_model.hpp"
 
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -636,6 +637,59 @@ void load_voxel_file(const std::string& path, VoxelGrid& v, int n_threads) {
     for (int k = 0; k < kMaxMaterials; ++k) v.density_max[k] = std::max(v.density_max[k], dmax[t][k]);
 }
 
+// Binary sidecar written by write_voxel_binary (report.cpp): same VoxelGrid as the text parse, without the parse.
+void load_voxel_binary(const std::string& path, VoxelGrid& v) {
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) fail(-1, "!! fopen ERROR load_voxels!! File %s does not exist!!", path.c_str());
+  char magic[8];
+  uint32_t version = 0, kind = 0, npal = 0;
+  bool ok = fread(magic, 1, 8, fp) == 8 && memcmp(magic, "MCGVOX1\n", 8) == 0 && fread(&version, 4, 1, fp) == 1 && version == 1 &&
+            fread(&kind, 4, 1, fp) == 1 && kind <= 2 && fread(v.n, 4, 3, fp) == 3 && fread(v.voxel_size, 4, 3, fp) == 3 &&
+            fread(&npal, 4, 1, fp) == 1 && npal <= 65536;
+  if (!ok || v.n[0] < 1 || v.n[1] < 1 || v.n[2] < 1) { fclose(fp); fail(-2, "!!Reading ERROR load_voxels!! %s is not a voxel sidecar of this engine.", path.c_str()); }
+  for (int k = 0; k < 3; ++k) {
+    v.size_bbox[k] = v.n[k] * v.voxel_size[k];
+    v.inv_voxel_size[k] = 1.0f / v.voxel_size[k];
+  }
+  const size_t nvox = v.count();
+  std::vector<uint32_t> pm(npal);
+  std::vector<float> pd(npal);
+  for (uint32_t k = 0; k < npal && ok; ++k) ok = fread(&pm[k], 4, 1, fp) == 1 && fread(&pd[k], 4, 1, fp) == 1;
+  v.material.assign(nvox, 0);
+  v.density.assign(nvox, 0.f);
+  if (ok && kind == 0) ok = fread(v.material.data(), 1, nvox, fp) == nvox && fread(v.density.data(), 4, nvox, fp) == nvox;
+  else if (ok && kind == 1) {
+    ok = fread(v.material.data(), 1, nvox, fp) == nvox;  // indices first, expanded in place below
+    if (ok)
+      for (size_t i = 0; i < nvox; ++i) {
+        const uint32_t k = v.material[i];
+        if (k >= npal) { ok = false; break; }
+        v.density[i] = pd[k];
+        v.material[i] = (uint8_t)pm[k];
+      }
+  } else if (ok) {
+    std::vector<uint16_t> idx(nvox);
+    ok = fread(idx.data(), 2, nvox, fp) == nvox;
+    if (ok)
+      for (size_t i = 0; i < nvox; ++i) {
+        const uint32_t k = idx[i];
+        if (k >= npal) { ok = false; break; }
+        v.density[i] = pd[k];
+        v.material[i] = (uint8_t)pm[k];
+      }
+  }
+  fclose(fp);
+  if (!ok) fail(-2, "!!ERROR load_voxels!! The voxel sidecar %s is truncated or corrupt.", path.c_str());
+  // the checks of the text loader (:2118-2134) and the per-material maximum density (:2136-2137)
+  for (int k = 0; k < kMaxMaterials; ++k) v.density_max[k] = -999.0f;
+  for (size_t i = 0; i < nvox; ++i) {
+    const int mat = v.material[i];
+    if (mat < 1 || mat > kMaxMaterials) fail(-2, "!!ERROR load_voxels!! Voxel material number out of range!! #mat=%d, voxel number=%zu", mat, i + 1);
+    if (v.density[i] < 1.0e-9f) fail(-2, "!!ERROR load_voxels!! Voxel density can not be 0 or negative: #mat=%d, density=%f, voxel number=%zu", mat, v.density[i], i + 1);
+    if (v.density[i] > v.density_max[mat - 1]) v.density_max[mat - 1] = v.density[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Material files (load_material, :2177-2443; format: SURVEY.md Appendix A.3)
 // ---------------------------------------------------------------------------------------------
@@ -793,7 +847,17 @@ void load_model(const std::string& input_path, HostModel& m) {
   parse_input_file(input_path, m);
   load_spectrum(m.cfg.file_spectrum, m.spectrum);
   build_ct_trajectory(m);
-  load_voxel_file(m.cfg.file_voxels, m.voxels);
+  {
+    // a binary sidecar next to the voxel file (geometry.voxbin, not older than the text) replaces the text parse
+    const std::string side = voxel_sidecar_path(m.cfg.file_voxels);
+    struct stat st_side, st_text;
+    const bool have_side = stat(side.c_str(), &st_side) == 0;
+    const bool have_text = stat(m.cfg.file_voxels.c_str(), &st_text) == 0;
+    const bool is_side = m.cfg.file_voxels.size() > 7 && m.cfg.file_voxels.compare(m.cfg.file_voxels.size() - 7, 7, ".voxbin") == 0;
+    if (is_side) load_voxel_binary(m.cfg.file_voxels, m.voxels);
+    else if (have_side && !getenv("MCGPU_IGNORE_VOXBIN") && (!have_text || st_side.st_mtime >= st_text.st_mtime)) load_voxel_binary(side, m.voxels);
+    else load_voxel_file(m.cfg.file_voxels, m.voxels);
+  }
   // the dose ROI may be given larger than the volume: clip its upper corner (load_voxels, :2058-2064)
   if (m.cfg.dose_roi[1] > -1)
     for (int ax = 0; ax < 3; ++ax) m.cfg.dose_roi[2 * ax + 1] = std::min(m.cfg.dose_roi[2 * ax + 1], m.voxels.n[ax] - 1);

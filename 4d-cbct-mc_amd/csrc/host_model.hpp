@@ -149,6 +149,7 @@ void finalize_projection_host(const HostModel& m, const uint64_t* image, unsigne
                               int n_threads = 0);
 MhaStack* mha_create(const std::string& path, int nx, int ny, int nslices, double sx, double sy);
 void mha_append(MhaStack* s, const float* plane);
+void mha_write_slice(MhaStack* s, int k, const float* plane);
 float mha_finish(MhaStack* s, bool replace_zeros);
 void mha_read(const std::string& path, int dims[3], std::vector<float>& data);
 void gaussian_filter_2d(float* img, int ny, int nx, double sigma_y, double sigma_x);
@@ -158,5 +159,12 @@ void normalize_stack(const std::string& total_path, const std::string& air_path,
 // Fast text/binary voxel writers (cbctmc/mc/voxel_data.pyx + mcgpu_geometry header fields)
 size_t write_voxel_file(const std::string& path, const int n[3], const float spacing_cm[3], const uint8_t* material,
                         const float* density, bool gzip);
+// Binary sidecar `<name>.voxbin` of a voxel file: the arrays the text parse would yield
+// (densities quantised through "%.6f" like the text), palette-compressed when the volume holds <= 65536 distinct
+// (material, density) pairs.  load_model() prefers a sidecar that is not older than the text file.
+size_t write_voxel_binary(const std::string& path, const int n[3], const float spacing_cm[3], const uint8_t* material,
+                          const float* density);
+void load_voxel_binary(const std::string& path, VoxelGrid& v);
+std::string voxel_sidecar_path(const std::string& voxel_file);  // geometry.vox[.gz] -> geometry.voxbin
 
 }  // namespace mcgpu

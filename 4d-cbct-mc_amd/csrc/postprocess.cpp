@@ -60,6 +60,7 @@ struct MhaStack {
   float min_positive = std::numeric_limits<float>::infinity();
   std::vector<uint64_t> zeros;  // element indices of exact zeros (patched by finish)
   bool zeros_overflow = false;
+  std::vector<unsigned char> have;  // slices written so far (random-access writes of a 4-D scan)
 };
 
 static std::string fmt_g(double v) {
@@ -92,7 +93,28 @@ MhaStack* mha_create(const std::string& path, int nx, int ny, int nslices, doubl
   return s;
 }
 
+// Write slice k (any order, each slice once): a 4-D scan visits the projections grouped by respiratory state.
+void mha_write_slice(MhaStack* s, int k, const float* plane) {
+  if (k < 0 || k >= s->nslices) throw Error(-3, "!!ERROR!! slice index outside " + s->path);
+  if (s->have.empty()) s->have.assign((size_t)s->nslices, 0);
+  if (s->have[k]) throw Error(-3, "!!ERROR!! slice written twice in " + s->path);
+  const size_t n = (size_t)s->nx * s->ny, base = (size_t)k * n;
+  for (size_t i = 0; i < n; ++i) {
+    const float v = plane[i];
+    if (v > 0.0f) { if (v < s->min_positive) s->min_positive = v; }
+    else if (v == 0.0f) {
+      if (s->zeros.size() < (1u << 26)) s->zeros.push_back(base + i);
+      else s->zeros_overflow = true;
+    }
+  }
+  fseek(s->fp, s->data_offset + (long)(base * 4), SEEK_SET);
+  if (fwrite(plane, sizeof(float), n, s->fp) != n) throw Error(-3, "!!ERROR!! short write to " + s->path);
+  s->have[k] = 1;
+  s->written++;
+}
+
 void mha_append(MhaStack* s, const float* plane) {
+  if (!s->have.empty()) throw Error(-3, "!!ERROR!! " + s->path + " is written by slice index; append is not allowed");
   if (s->written >= s->nslices) throw Error(-3, "!!ERROR!! more planes appended to " + s->path + " than declared");
   const size_t n = (size_t)s->nx * s->ny, base = (size_t)s->written * n;
   for (size_t i = 0; i < n; ++i) {

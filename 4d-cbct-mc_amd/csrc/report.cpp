@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <unordered_map>
+#include <vector>
 
 #include "host_model.hpp"
 
@@ -245,6 +247,85 @@ size_t write_voxel_file(const std::string& path, const int n[3], const float spa
     emit("\n", 1);
   }
   if (gz) gzclose(gz); else fclose(fp);
+  return bytes;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Binary sidecar (format: magic "MCGVOX1\n", u32 version, u32 kind {0 raw, 1 palette+u8, 2 palette+u16}, i32 n[3],
+// f32 voxel_size[3], u32 palette_count, palette {u32 material, f32 density}..., then the voxel data, x fastest)
+// ---------------------------------------------------------------------------------------------
+std::string voxel_sidecar_path(const std::string& voxel_file) {
+  std::string s = voxel_file;
+  auto strip = [&](const char* ext) {
+    const size_t n = strlen(ext);
+    if (s.size() > n && s.compare(s.size() - n, n, ext) == 0) s.resize(s.size() - n);
+  };
+  strip(".gz");
+  strip(".vox");
+  return s + ".voxbin";
+}
+
+size_t write_voxel_binary(const std::string& path, const int n[3], const float spacing_cm[3], const uint8_t* material,
+                          const float* density) {
+  const size_t nvox = (size_t)n[0] * n[1] * n[2];
+  // densities as the text file carries them: "%.6f", read back with %f (voxel_data.pyx:25, MC-GPU_v1.3.cu:2117)
+  std::unordered_map<uint32_t, float> quantised;
+  auto q6 = [&](float d) {
+    uint32_t b;
+    memcpy(&b, &d, 4);
+    auto it = quantised.find(b);
+    if (it != quantised.end()) return it->second;
+    char t[64];
+    snprintf(t, sizeof t, "%.6f", (double)d);
+    const float v = strtof(t, nullptr);
+    quantised.emplace(b, v);
+    return v;
+  };
+  std::unordered_map<uint64_t, uint32_t> index_of;
+  std::vector<uint32_t> pal_mat;
+  std::vector<float> pal_dens;
+  std::vector<uint16_t> idx(nvox);
+  std::vector<float> dq(nvox);
+  bool overflow = false;
+  uint64_t last_key = ~0ull;
+  uint32_t last_idx = 0;
+  for (size_t i = 0; i < nvox; ++i) {
+    const float d = q6(density[i]);
+    dq[i] = d;
+    if (overflow) continue;
+    uint32_t db;
+    memcpy(&db, &d, 4);
+    const uint64_t key = ((uint64_t)material[i] << 32) | db;
+    if (key != last_key) {
+      auto it = index_of.find(key);
+      if (it == index_of.end()) {
+        if (index_of.size() >= 65536) { overflow = true; continue; }
+        last_idx = (uint32_t)index_of.size();
+        index_of.emplace(key, last_idx);
+        pal_mat.push_back(material[i]);
+        pal_dens.push_back(d);
+      } else last_idx = it->second;
+      last_key = key;
+    }
+    idx[i] = (uint16_t)last_idx;
+  }
+  const uint32_t kind = overflow ? 0u : (index_of.size() <= 256 ? 1u : 2u);
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) throw Error(-3, "!!ERROR!! can not open " + path + " for writing");
+  size_t bytes = 0;
+  auto put = [&](const void* p, size_t nb) { bytes += fwrite(p, 1, nb, fp); };
+  const uint32_t version = 1, npal = overflow ? 0u : (uint32_t)index_of.size();
+  put("MCGVOX1\n", 8);
+  put(&version, 4); put(&kind, 4); put(n, 12); put(spacing_cm, 12); put(&npal, 4);
+  for (uint32_t k = 0; k < npal; ++k) { put(&pal_mat[k], 4); put(&pal_dens[k], 4); }
+  if (kind == 0) { put(material, nvox); put(dq.data(), nvox * 4); }
+  else if (kind == 1) {
+    std::vector<uint8_t> i8(nvox);
+    for (size_t i = 0; i < nvox; ++i) i8[i] = (uint8_t)idx[i];
+    put(i8.data(), nvox);
+  } else put(idx.data(), nvox * 2);
+  if (fclose(fp) != 0) throw Error(-3, "!!ERROR!! " + path + " could not be written");
   return bytes;
 }
 

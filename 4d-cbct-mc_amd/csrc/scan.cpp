@@ -105,7 +105,9 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       if (opt->write_ascii) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, hipHostMallocDefault));
       HIP_OK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     }
-    if (opt->write_stacks) {
+    const bool shared = opt->shared_stacks != nullptr;  // 4-D: the caller owns stacks that several scans fill by slice index
+    if (shared && !opt->slice_of_projection) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: shared_stacks needs slice_of_projection"};
+    if (opt->write_stacks && !shared) {
       static const char* kNames[3] = {"projections_total.mha", "projections_unscattered.mha", "projections_scattered.mha"};
       for (int k = 0; k < 3; ++k) ABI_OK(mcgpu_stack_create((folder + "/" + kNames[k]).c_str(), cx, (int)nz, count, sx, sy, &stacks[k]));
     }
@@ -127,7 +129,10 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
           return;
         }
         int wrc = 0;
-        if (opt->write_stacks)
+        if (shared)
+          for (int k = 0; k < 3 && wrc == 0; ++k)
+            wrc = mcgpu_stack_write_slice(opt->shared_stacks[k], opt->slice_of_projection[i], planes_host[b] + (size_t)k * plane);
+        else if (opt->write_stacks)
           for (int k = 0; k < 3 && wrc == 0; ++k) wrc = mcgpu_stack_append(stacks[k], planes_host[b] + (size_t)k * plane);
         if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, 0.0, nullptr);
         std::lock_guard<std::mutex> lk(sh.mu);
@@ -181,7 +186,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       if (sh.abort) throw ScanError{-3, sh.error};
     }
     float repl[3] = {0.f, 0.f, 0.f};
-    if (opt->write_stacks) {
+    if (opt->write_stacks && !shared) {
       for (int k = 0; k < 3; ++k) {
         mcgpu_stack* s = stacks[k];
         stacks[k] = nullptr;

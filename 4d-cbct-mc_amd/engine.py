@@ -26,9 +26,10 @@ ABI_SYMBOLS = (
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
-    "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_finish",
-    "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan",
-    "mcgpu_write_voxel_file", "mcgpu_kat_rng", "mcgpu_kat_math",
+    "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
+    "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
+    "mcgpu_warp_volume",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math",
 )
 
 
@@ -37,7 +38,8 @@ class ScanOptions(C.Structure):
     _fields_ = [("mode", C.c_int), ("first_projection", C.c_int), ("num_projections", C.c_int),
                 ("histories_per_projection", C.c_ulonglong), ("crop_nx", C.c_int), ("write_ascii", C.c_int), ("write_stacks", C.c_int),
                 ("output_folder", C.c_char_p), ("air_stack", C.c_char_p), ("air_sigma_y", C.c_double), ("air_sigma_x", C.c_double),
-                ("pixel_spacing_x", C.c_double), ("pixel_spacing_y", C.c_double)]
+                ("pixel_spacing_x", C.c_double), ("pixel_spacing_y", C.c_double),
+                ("shared_stacks", C.POINTER(C.c_void_p)), ("slice_of_projection", C.POINTER(C.c_int))]
 
 
 class ScanReport(C.Structure):
@@ -95,11 +97,16 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_finalize_projection_host.argtypes = [vp, vp, cull, ci, vp]
     lib.mcgpu_stack_create.argtypes = [cp, ci, ci, ci, C.c_double, C.c_double, C.POINTER(vp)]
     lib.mcgpu_stack_append.argtypes = [vp, vp]
+    lib.mcgpu_stack_write_slice.argtypes = [vp, ci, vp]
+    lib.mcgpu_set_projection_angles.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    lib.mcgpu_set_geometry_arrays.argtypes = [vp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
+    lib.mcgpu_warp_volume.argtypes = [vp, C.POINTER(ci), vp, vp, vp, ci, C.c_float, vp, vp]
     lib.mcgpu_stack_finish.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.mcgpu_stack_read.argtypes = [cp, C.POINTER(ci), vp, C.c_size_t]
     lib.mcgpu_normalize_stack.argtypes = [cp, cp, C.c_double, C.c_double, cp, C.c_double, C.c_double]
     lib.mcgpu_run_scan.argtypes = [vp, C.POINTER(ScanOptions), C.POINTER(ScanReport)]
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
+    lib.mcgpu_write_voxel_binary.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     if path is None:
@@ -131,6 +138,23 @@ def write_voxel_file(path, n, spacing_cm, material_zyx: np.ndarray, density_zyx:
                                                  m.ctypes.data, d.ctypes.data, int(bool(gzip))))
 
 
+def write_voxel_binary(path, n, spacing_cm, material_zyx: np.ndarray, density_zyx: np.ndarray):
+    """Binary sidecar (`geometry.voxbin`) the engine prefers over the text voxel file of the same stem."""
+    m = np.ascontiguousarray(material_zyx, dtype=np.uint8)
+    d = np.ascontiguousarray(density_zyx, dtype=np.float32)
+    assert m.size == d.size == int(n[0]) * int(n[1]) * int(n[2])
+    _check(load_library().mcgpu_write_voxel_binary(str(path).encode(), (C.c_int * 3)(*map(int, n)), (C.c_float * 3)(*map(float, spacing_cm)),
+                                                   m.ctypes.data, d.ctypes.data))
+
+
+def voxel_sidecar_path(voxel_file) -> Path:
+    s = str(voxel_file)
+    for ext in (".gz", ".vox"):
+        if s.endswith(ext):
+            s = s[: -len(ext)]
+    return Path(s + ".voxbin")
+
+
 class StackWriter:
     """MetaImage float32 stack written plane by plane (the reference's `projections_to_itk` + `sitk.WriteImage`)."""
 
@@ -144,6 +168,12 @@ class StackWriter:
         a = np.ascontiguousarray(plane, dtype=np.float32)
         assert a.shape == self.shape
         _check(self.lib.mcgpu_stack_append(self.h, a.ctypes.data))
+
+    def write_slice(self, k: int, plane: np.ndarray):
+        """Random-access write (each slice once; not mixed with append): 4-D scans fill the stack grouped by respiratory state."""
+        a = np.ascontiguousarray(plane, dtype=np.float32)
+        assert a.shape == self.shape
+        _check(self.lib.mcgpu_stack_write_slice(self.h, int(k), a.ctypes.data))
 
     def finish(self, replace_zeros: bool = True) -> float:
         v = C.c_float()
@@ -298,10 +328,48 @@ class Context:
         _check(self.lib.mcgpu_finalize_projection(self.h, C.c_void_p(image_dev_ptr), int(total_histories), int(crop_nx), C.c_void_p(planes_dev_ptr),
                                                   int(clear), C.c_void_p(stream)))
 
+    # -- 4-D: several (geometry, projection angles) jobs on one resident context (cbctmc/mc/simulation.py:527-710)
+    def set_projection_angles(self, angles_deg):
+        """Explicit projection angles [deg]; pose 0 stays the input file's (pass the first angle twice like the reference
+        and start the scan at first_projection=1)."""
+        a = np.ascontiguousarray(angles_deg, dtype=np.float32)
+        _check(self.lib.mcgpu_set_projection_angles(self.h, int(a.size), a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_geometry_arrays(self, n, spacing_cm, material_zyx: np.ndarray, density_zyx: np.ndarray):
+        """Replace the voxel volume from arrays ([z][y][x]); material tables are rebuilt and everything is uploaded again."""
+        m = np.ascontiguousarray(material_zyx, dtype=np.uint8)
+        d = np.ascontiguousarray(density_zyx, dtype=np.float32)
+        assert m.size == d.size == int(n[0]) * int(n[1]) * int(n[2])
+        _check(self.lib.mcgpu_set_geometry_arrays(self.h, (C.c_int * 3)(*map(int, n)), (C.c_float * 3)(*map(float, spacing_cm)),
+                                                  m.ctypes.data, d.ctypes.data))
+
+    def set_geometry(self, geometry):
+        """An `MCGeometry` of the Python mirror, in the orientation its voxel file would have (geo.py:589-599)."""
+        mats, dens, spacing_cm = geometry.mcgpu_arrays()
+        nx, ny, nz = mats.shape
+        self.set_geometry_arrays((nx, ny, nz), spacing_cm, np.transpose(mats, (2, 1, 0)), np.transpose(dens, (2, 1, 0)))
+
+    def warp_volume(self, material_zyx: np.ndarray, density_zyx: np.ndarray, displacement: np.ndarray, default_material: int, default_density: float):
+        """Nearest-neighbour warp on the GPU: out[x] = in[rint(x + u(x))]; displacement [3, nz, ny, nx] (x, y, z components, voxels)."""
+        m = np.ascontiguousarray(material_zyx, dtype=np.uint8)
+        d = np.ascontiguousarray(density_zyx, dtype=np.float32)
+        u = np.ascontiguousarray(displacement, dtype=np.float32)
+        nz, ny, nx = m.shape
+        assert d.shape == m.shape and u.shape == (3, nz, ny, nx)
+        mo, do = np.empty_like(m), np.empty_like(d)
+        _check(self.lib.mcgpu_warp_volume(self.h, (C.c_int * 3)(nx, ny, nz), m.ctypes.data, d.ctypes.data, u.ctypes.data, int(default_material),
+                                          float(default_density), mo.ctypes.data, do.ctypes.data))
+        return mo, do
+
     def run_scan(self, mode="fast", first_projection=0, num_projections=0, histories=0, crop_nx=0, write_ascii=False, write_stacks=True,
-                 output_folder=None, air_stack=None, air_sigma=(10.0, 10.0), pixel_spacing=(0.0, 0.0)) -> dict:
-        """The whole projection loop as a device/host pipeline (mcgpu_run_scan); returns the timing report."""
+                 output_folder=None, air_stack=None, air_sigma=(10.0, 10.0), pixel_spacing=(0.0, 0.0), shared_stacks=None,
+                 slice_of_projection=None) -> dict:
+        """The whole projection loop as a device/host pipeline (mcgpu_run_scan); returns the timing report.
+        `shared_stacks` = three open StackWriters (total, unscattered, scattered) filled by slice index (4-D scans)."""
         o = ScanOptions()
+        if shared_stacks is not None:
+            self._keep = ((C.c_void_p * 3)(*[s.h for s in shared_stacks]), (C.c_int * len(slice_of_projection))(*map(int, slice_of_projection)))
+            o.shared_stacks, o.slice_of_projection = self._keep[0], self._keep[1]
         o.mode, o.first_projection, o.num_projections = _MODES[mode], int(first_projection), int(num_projections)
         o.histories_per_projection, o.crop_nx = int(histories), int(crop_nx)
         o.write_ascii, o.write_stacks = int(bool(write_ascii)), int(bool(write_stacks))

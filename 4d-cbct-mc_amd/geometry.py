@@ -52,11 +52,19 @@ class MCGeometry:
         spacing_cm = (self.image_spacing[1] / 10.0, self.image_spacing[0] / 10.0, self.image_spacing[2] / 10.0)
         return mats, dens, spacing_cm
 
-    def save_mcgpu_geometry(self, filepath, compress: bool = True, engine=None):
+    def save_mcgpu_geometry(self, filepath, compress: bool = True, engine=None, binary_sidecar: bool = False):
+        """Text voxel file of the reference (geo.py:579-623).  `binary_sidecar` (needs `engine`) also writes
+        `<stem>.voxbin`, which the engine loads instead of parsing the text."""
         if not (self.densities > 0.0).all():
             raise ValueError("Density can not be zero or negative")
         mats, dens, spacing_cm = self.mcgpu_arrays()
         write_vox(filepath, mats, dens, spacing_cm, compress=compress, engine=engine)
+        if binary_sidecar:
+            if engine is None:
+                raise ValueError("the binary sidecar is written by the engine library")
+            nx, ny, nz = mats.shape
+            engine.write_voxel_binary(engine.voxel_sidecar_path(filepath), (nx, ny, nz), spacing_cm,
+                                      np.transpose(mats, (2, 1, 0)), np.transpose(dens, (2, 1, 0)))
 
 
 def write_vox(filepath, materials_xyz: np.ndarray, densities_xyz: np.ndarray, spacing_cm, compress=True, engine=None):

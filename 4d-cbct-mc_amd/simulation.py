@@ -144,7 +144,7 @@ class MCSimulation:
         self.dose_roi = dose_roi
 
     def prepare_simulation(self, output_folder, geometry_output_folder=None, output_suffix="", gpu_ids=(0,),
-                           force_geometry_recompile=False, compress_geometry=True, engine=None) -> Path:
+                           force_geometry_recompile=False, compress_geometry=True, engine=None, binary_sidecar=False) -> Path:
         """Write geometry<suffix>.vox.gz and input<suffix>.in (sim.py:95-174); returns the input path."""
         output_folder = Path(output_folder)
         geometry_output_folder = Path(geometry_output_folder or output_folder)
@@ -154,7 +154,8 @@ class MCSimulation:
         input_filepath = output_folder / f"input{output_suffix}.in"
         geometry_filepath = geometry_output_folder / (f"geometry{output_suffix}.vox" + (".gz" if compress_geometry else ""))
         if not geometry_filepath.exists() or force_geometry_recompile:
-            self.geometry.save_mcgpu_geometry(geometry_filepath, compress=compress_geometry, engine=engine)
+            self.geometry.save_mcgpu_geometry(geometry_filepath, compress=compress_geometry, engine=engine,
+                                              binary_sidecar=binary_sidecar and engine is not None)
         text = create_mcgpu_input(
             voxel_geometry_filepath=geometry_filepath, material_filepaths=self.material_filepaths,
             xray_spectrum_filepath=self.xray_spectrum_filepath,
@@ -249,3 +250,102 @@ class MCSimulation:
         if clean:
             for f in files:
                 f.unlink()
+
+
+class MCSimulation4D:
+    """`MCSimulation4D` (sim.py:430-710) on ONE resident engine context.
+
+    The reference launches the engine once per unique respiratory state: warp the geometry on the CPU, write a
+    `.vox.gz`, start a container, parse 134 M text lines, simulate that state's projections (the first angle twice,
+    sim.py:658-660), and finally read every ASCII file back to stack them.  Here the context is created once; per
+    state the geometry is warped on the GPU, handed over as arrays, the state's angles are set, and the scan
+    pipeline writes its projections straight into their slices of the three shared stacks.
+
+    `correspondence_model` is anything with `predict(np.array([signal, dt_signal])) -> displacement field
+    [3, x, y, z]` in voxels (the reference's CorrespondenceModel.predict, sim.py:477)."""
+
+    def __init__(self, correspondence_model, geometry, material_filepaths, xray_spectrum_filepath, n_histories=DEFAULTS.n_histories,
+                 n_projections=DEFAULTS.n_projections, frame_rate=15.0, angle_between_projections=DEFAULTS.angle_between_projections,
+                 random_seed=DEFAULTS.random_seed, **sim_kwargs):
+        self.correspondence_model = correspondence_model
+        self.geometry = geometry
+        self.material_filepaths = list(material_filepaths)
+        self.xray_spectrum_filepath = xray_spectrum_filepath
+        self.n_histories = int(n_histories)
+        self.n_projections = n_projections
+        self.frame_rate = frame_rate
+        self.angle_between_projections = angle_between_projections
+        self.random_seed = random_seed
+        self.sim_kwargs = sim_kwargs
+
+    def warp_geometry(self, ctx, signal: float, dt_signal: float):
+        """`_warp_geometry` (sim.py:473-478) + `MCGeometry.warp` (geo.py:386-439), nearest neighbour, air outside, on the GPU."""
+        import numpy as np
+        from .geometry import MCGeometry
+        from .materials import MATERIALS_125KEV, material_number
+        field = np.asarray(self.correspondence_model.predict(np.array([signal, dt_signal])), dtype=np.float32)
+        if field.ndim == 5:
+            field = field[0]
+        mats, dens = self.geometry.materials, self.geometry.densities  # [x, y, z]
+        # engine arrays are [z][y][x]; the field's components stay (x, y, z)
+        u = np.ascontiguousarray(np.transpose(field, (0, 3, 2, 1)))
+        m, d = ctx.warp_volume(np.transpose(mats, (2, 1, 0)), np.transpose(dens, (2, 1, 0)), u, material_number("air"), MATERIALS_125KEV["air"])
+        return MCGeometry(np.transpose(m, (2, 1, 0)), np.transpose(d, (2, 1, 0)), self.geometry.image_spacing)
+
+    def run_simulation(self, respiratory_signal, respiratory_signal_quantization, output_folder, engine, gpu_ids=(0,), mode="fast",
+                       run_air_simulation=False, air_projection_denoise_kernel_size=(10, 10), air_n_histories=int(5e10), start_angle=270.0,
+                       force_rerun=False):
+        import numpy as np
+        from .respiratory import RespiratorySignal
+        output_folder = Path(output_folder)
+        if MCSimulation._already_simulated(output_folder) and not force_rerun:
+            return None
+        output_folder.mkdir(parents=True, exist_ok=True)
+        gpu_ids = (gpu_ids,) if isinstance(gpu_ids, int) else tuple(gpu_ids)
+        sig = respiratory_signal.resample(self.frame_rate)  # one signal value per projection (sim.py:557-563)
+        signal, dt_signal = sig.signal[: self.n_projections], sig.dt_signal[: self.n_projections]
+        np.savetxt(output_folder / "signal.txt", np.stack((signal, dt_signal)).T, fmt="%.6f",
+                   header="original respiratory signal and its derivative\nsignal quantization: None\nsignal dt_signal")
+        if respiratory_signal_quantization:
+            signal = RespiratorySignal.quantize_signal(signal, n_bins=respiratory_signal_quantization)
+            dt_signal = RespiratorySignal.quantize_signal(dt_signal, n_bins=respiratory_signal_quantization)
+        np.savetxt(output_folder / "signal_quantized.txt", np.stack((signal, dt_signal)).T, fmt="%.6f",
+                   header=f"quantized respiratory signal and its derivative\nsignal quantization: {respiratory_signal_quantization} bins\nsignal dt_signal")
+        unique = RespiratorySignal.get_unique_signals(signal=signal, dt_signal=dt_signal)
+        n_proj = len(signal)
+        base = MCSimulation(self.geometry, self.material_filepaths, self.xray_spectrum_filepath, n_histories=self.n_histories,
+                            projection_angles=[start_angle, start_angle + self.angle_between_projections],
+                            angle_between_projections=self.angle_between_projections, random_seed=self.random_seed, **self.sim_kwargs)
+        air_stack = None
+        if run_air_simulation:
+            MCSimulation.run_air_simulation(output_folder, engine, self.material_filepaths, self.xray_spectrum_filepath, n_histories=air_n_histories,
+                                            gpu_ids=gpu_ids, mode=mode, **self.sim_kwargs)
+            air_stack = output_folder / MCSimulation._AIR_SIMULATION_FOLDER / "projections_total.mha"
+        input_filepath = base.prepare_simulation(output_folder, gpu_ids=gpu_ids, engine=engine, binary_sidecar=True)
+        nx_det, nz_det = base.n_detector_pixels
+        half_fan = DEFAULTS.n_detector_pixels_half_fan[0] if tuple(base.n_detector_pixels) == tuple(DEFAULTS.n_detector_pixels) else 0
+        cx = half_fan or nx_det
+        stacks = [engine.StackWriter(output_folder / f"projections_{m}.mha", cx, nz_det, n_proj, MCSimulation.STACK_PIXEL_SPACING)
+                  for m in ("total", "unscattered", "scattered")]
+        geometries = {}
+        ctx = engine.create(str(input_filepath), device=gpu_ids[0])
+        try:
+            for (s, ds), indices in unique.items():
+                ctx.set_geometry(self.warp_geometry(ctx, s, ds))
+                angles = [start_angle + i * self.angle_between_projections for i in indices]
+                ctx.set_projection_angles(angles[0:1] + angles)  # pose 0 is the input file's: skipped below (sim.py:658-660)
+                ctx.run_scan(mode=mode, first_projection=1, num_projections=len(angles), crop_nx=half_fan, write_stacks=False,
+                             output_folder=output_folder, shared_stacks=stacks, slice_of_projection=indices)
+                for a in angles:
+                    geometries[a] = {"signal": float(s), "dt_signal": float(ds), "signal_quantization": respiratory_signal_quantization}
+        finally:
+            ctx.close()
+        for w in stacks:
+            w.finish(replace_zeros=True)
+        if air_stack is not None:
+            engine.normalize_stack(output_folder / "projections_total.mha", air_stack, output_folder / "projections_total_normalized.mha",
+                                   sigma=air_projection_denoise_kernel_size, spacing=MCSimulation.STACK_PIXEL_SPACING)
+        import yaml
+        with open(output_folder / "projection_geometries.yaml", "wt") as f:
+            yaml.dump(dict(sorted(geometries.items())), f)
+        return {"unique_states": len(unique), "projections": n_proj}

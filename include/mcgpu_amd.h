@@ -136,6 +136,7 @@ int mcgpu_finalize_projection_host(const mcgpu_ctx *ctx, const uint64_t *image_h
 typedef struct mcgpu_stack mcgpu_stack;
 int mcgpu_stack_create(const char *path, int nx, int ny, int nslices, double spacing_x, double spacing_y, mcgpu_stack **out);
 int mcgpu_stack_append(mcgpu_stack *stack, const float *plane);
+int mcgpu_stack_write_slice(mcgpu_stack *stack, int slice, const float *plane); /* any order, each slice once; not mixed with append */
 int mcgpu_stack_finish(mcgpu_stack *stack, int replace_zeros, float *replacement_value);
 int mcgpu_stack_read(const char *path, int dims3[3], float *data /* NULL: dims only */, size_t capacity_elements);
 /* normalize_projections (projection.py:96-115): out = log(gaussian_filter(air, (sigma_y, sigma_x)) / total), scipy's
@@ -157,6 +158,10 @@ typedef struct mcgpu_scan_options {
   const char *air_stack;                        /* air scan's projections_total.mha: also write projections_total_normalized.mha */
   double air_sigma_y, air_sigma_x;              /* gaussian denoising of the air projection (reference default 10, 10) */
   double pixel_spacing_x, pixel_spacing_y;      /* MetaImage spacing [mm]; 0 = detector pixel size of the input file */
+  /* 4-D scans: three caller-owned stacks {total, unscattered, scattered} shared by several scans; projection i of THIS
+   * scan (i = 0 .. num_projections-1) is written to slice slice_of_projection[i].  The caller finishes the stacks. */
+  mcgpu_stack **shared_stacks;
+  const int *slice_of_projection;
 } mcgpu_scan_options;
 typedef struct mcgpu_scan_report {
   int projections;
@@ -166,10 +171,32 @@ typedef struct mcgpu_scan_report {
 } mcgpu_scan_report;
 int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
 
+/* ---- 4-D: one resident context for many (geometry, projection angles) jobs (cbctmc/mc/simulation.py:527-710 launches the
+ * engine once per respiratory state) ----
+ * mcgpu_set_projection_angles: the explicit-angle list of SECTION ANGLES OF PROJ (MC-GPU_v1.3.cu:1484-1533) replaced at run
+ *   time; poses are rebuilt as set_CT_trajectory does (:3280-3434) -- pose 0 stays the input file's (:3313), which is why the
+ *   reference passes the first angle twice (simulation.py:658-660); skip it with mcgpu_scan_options::first_projection = 1.
+ * mcgpu_set_geometry_arrays: replace the voxel volume from arrays ([z][y][x], as mcgpu_write_voxel_file takes them); densities
+ *   pass through the "%.6f" of the voxel file, the material tables are rebuilt (their Woodcock majorant depends on the
+ *   volume) and everything is uploaded again.
+ * mcgpu_warp_volume: nearest-neighbour warp of (material, density) by a displacement field [3][nz][ny][nx] in voxel units,
+ *   out[x] = in[rint(x + u(x))], default outside (geometry.py:386-439: nearest-neighbour grid sampling of the vroc package), on the
+ *   context's GPU. */
+int mcgpu_set_projection_angles(mcgpu_ctx *ctx, int n, const float *angles_deg);
+int mcgpu_set_geometry_arrays(mcgpu_ctx *ctx, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density);
+int mcgpu_warp_volume(mcgpu_ctx *ctx, const int n[3], const uint8_t *material, const float *density, const float *displacement,
+                      int default_material, float default_density, uint8_t *material_out, float *density_out);
+
 /* Voxel geometry writer (cbctmc/mc/voxel_data.pyx:12-72 + mcgpu_geometry.jinja2 header fields):
  * material/density are [z][y][x] contiguous, spacing in cm. */
 int mcgpu_write_voxel_file(const char *path, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density,
                            int gzip);
+
+/* Binary sidecar of a voxel file (`geometry.vox[.gz]` -> `geometry.voxbin`): the arrays the text parse would yield (densities
+ * quantised through "%.6f" exactly like cbctmc/mc/voxel_data.pyx:25 + MC-GPU_v1.3.cu:2117), palette-compressed.  mcgpu_create
+ * prefers a sidecar that is not older than the text file: a 512^3 volume loads in well under a second instead of the
+ * 134 M-line text parse per process launch. */
+int mcgpu_write_voxel_binary(const char *path, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density);
 
 /* Device-side known-answer hooks used by the parity tests (each runs a tiny kernel on the context's device). */
 int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n, float *out_f32);

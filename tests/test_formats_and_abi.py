@@ -156,3 +156,32 @@ def test_catphan_recipe_and_padding():
     p = g.pad_to_shape((104, 100, 108))
     assert p.image_shape == (104, 100, 108) and np.array_equal(p.materials[2:102, :, 4:104], g.materials)
     assert cases.simulation.source_position_for((305.0, 300.0, 152.0)) == (152.5, -850.0, 76.0)
+
+
+def test_binary_voxel_sidecar_equals_text_parse(engine, tmp_path):
+    """geometry.voxbin yields exactly the host model of the text file it shadows."""
+    rng = np.random.default_rng(4)
+    g = cases.geometry.MCBoxGeometry(shape=(14, 9, 11), image_spacing=(7.0, 9.0, 11.0), material="h2o")
+    g.materials[3:9, 2:6, 4:8] = cases.materials.material_number("bone_050")
+    g.densities[:] = rng.uniform(0.001, 2.2, g.densities.shape).astype(np.float32)  # more digits than "%.6f" keeps
+    sim_kw = dict(n_projections=1, n_histories=1000, **cases.SMALL_DET)
+    a, b = tmp_path / "text", tmp_path / "bin"
+    for folder, side in ((a, False), (b, True)):
+        sim = cases.simulation.MCSimulation(g, cases.material_files(), cases.spectrum_file(), **sim_kw)
+        sim.prepare_simulation(folder, compress_geometry=True, engine=engine, binary_sidecar=side)
+    assert (b / "geometry.voxbin").exists() and not (a / "geometry.voxbin").exists()
+    with engine.create(a / "input.in", device=-1) as ta, engine.create(b / "input.in", device=-1) as tb:
+        for name in ("voxel_mat_dens", "density_max", "mfp_woodcock", "size_bbox", "inv_voxel_size"):
+            assert np.array_equal(ta.host_table(name), tb.host_table(name)), name
+    # the sidecar is what gets read: corrupting the text body goes unnoticed, a stale sidecar is ignored
+    text = gzip.open(b / "geometry.vox.gz", "rt").read()
+    import os, time
+    with gzip.open(b / "geometry.vox.gz", "wt") as f:
+        f.write(text.replace("2 1.4", "9 1.4", 1) if "2 1.4" in text else text[: len(text) // 2])
+    os.utime(b / "geometry.voxbin", (time.time() + 5, time.time() + 5))
+    with engine.create(b / "input.in", device=-1) as tb2, engine.create(a / "input.in", device=-1) as ta2:
+        assert np.array_equal(tb2.host_table("voxel_mat_dens"), ta2.host_table("voxel_mat_dens"))
+    (b / "geometry.voxbin").write_bytes(b"not a sidecar")
+    with pytest.raises(engine.EngineError) as e:
+        engine.create(b / "input.in", device=-1)
+    assert "ERROR" in e.value.message
