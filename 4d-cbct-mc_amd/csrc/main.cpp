@@ -90,6 +90,7 @@ int main(int argc, char** argv) {
     mcgpu_scan_options so;
     memset(&so, 0, sizeof so);
     so.mode = mode;
+    so.progress = 1;
     so.crop_nx = crop_nx;
     so.write_ascii = write_out ? 1 : 0;
     so.write_stacks = stacks ? 1 : 0;

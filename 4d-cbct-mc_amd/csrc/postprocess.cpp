@@ -134,21 +134,20 @@ void mha_append(MhaStack* s, const float* plane) {
 float mha_finish(MhaStack* s, bool replace_zeros) {
   const float fill = s->min_positive;
   if (replace_zeros && std::isfinite(fill)) {
-    if (!s->zeros_overflow) {
-      for (uint64_t idx : s->zeros) {
-        fseek(s->fp, s->data_offset + (long)(idx * 4), SEEK_SET);
-        fwrite(&fill, 4, 1, s->fp);
-      }
-    } else {  // too many to remember: rewrite in one sequential pass
-      const size_t n = (size_t)s->nx * s->ny;
-      std::vector<float> buf(n);
-      for (int k = 0; k < s->written; ++k) {
-        fseek(s->fp, s->data_offset + (long)((size_t)k * n * 4), SEEK_SET);
-        if (fread(buf.data(), 4, n, s->fp) != n) break;
-        for (float& v : buf) if (v == 0.0f) v = fill;
-        fseek(s->fp, s->data_offset + (long)((size_t)k * n * 4), SEEK_SET);
-        fwrite(buf.data(), 4, n, s->fp);
-      }
+    // slice-wise read-modify-write (one seek per slice, not per zero: low-statistics stacks hold millions of zeros)
+    const size_t n = (size_t)s->nx * s->ny;
+    std::vector<unsigned char> dirty((size_t)s->nslices, s->zeros_overflow ? 1 : 0);
+    if (!s->zeros_overflow)
+      for (uint64_t idx : s->zeros) dirty[idx / n] = 1;
+    std::vector<float> buf(n);
+    for (int k = 0; k < s->nslices; ++k) {
+      if (!dirty[k]) continue;
+      fseek(s->fp, s->data_offset + (long)((size_t)k * n * 4), SEEK_SET);
+      if (fread(buf.data(), 4, n, s->fp) != n) continue;  // slice never written: reported below
+      for (float& v : buf)
+        if (v == 0.0f) v = fill;
+      fseek(s->fp, s->data_offset + (long)((size_t)k * n * 4), SEEK_SET);
+      fwrite(buf.data(), 4, n, s->fp);
     }
   }
   const bool complete = s->written == s->nslices;

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -57,6 +58,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     int queued = 0, written = 0;  // projections handed to / finished by the writer
     bool abort = false;
     std::string error;
+    double writer_s = 0.0;
   } sh;
   int rc = 0;
   try {
@@ -96,13 +98,15 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     }
 
     HIP_OK(hipSetDevice((int)dev));
+    const unsigned int pinned_flags = getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent;
     HIP_OK(hipStreamCreate(&stream));
     HIP_OK(hipMalloc(&image_dev, words * 8));
     HIP_OK(hipMemsetAsync(image_dev, 0, words * 8, stream));
     for (int b = 0; b < 2; ++b) {
       HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));
-      HIP_OK(hipHostMalloc((void**)&planes_host[b], 3 * plane * 4, hipHostMallocDefault));
-      if (opt->write_ascii) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, hipHostMallocDefault));
+      // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte; the event orders the accesses
+      HIP_OK(hipHostMalloc((void**)&planes_host[b], 3 * plane * 4, pinned_flags));
+      if (opt->write_ascii) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, pinned_flags));
       HIP_OK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     }
     const bool shared = opt->shared_stacks != nullptr;  // 4-D: the caller owns stacks that several scans fill by slice index
@@ -128,6 +132,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
           sh.cv.notify_all();
           return;
         }
+        const double tw0 = now_s();
         int wrc = 0;
         if (shared)
           for (int k = 0; k < 3 && wrc == 0; ++k)
@@ -136,6 +141,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
           for (int k = 0; k < 3 && wrc == 0; ++k) wrc = mcgpu_stack_append(stacks[k], planes_host[b] + (size_t)k * plane);
         if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, 0.0, nullptr);
         std::lock_guard<std::mutex> lk(sh.mu);
+        sh.writer_s += now_s() - tw0;
         if (wrc != 0) { sh.error = mcgpu_last_error(); sh.abort = true; }
         sh.written = i + 1;
         sh.cv.notify_all();
@@ -157,7 +163,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
         sh.cv.wait(lk, [&] { return sh.written >= i - 1 || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
-      if (nproj_all != 1) {
+      if (nproj_all != 1 && opt->progress) {
         printf("\n\n\n   << Simulating Projection %d of %d >>\n\n\n", p + 1, (int)nproj_all);  // cbctmc/mc/simulation.py:200-219 parses this
         fflush(stdout);
       }
@@ -202,6 +208,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       report->seconds_total = now_s() - t0;
       report->seconds_kernels = kernel_s;
       report->seconds_after_last_kernel = now_s() - t_last_kernel;
+      report->seconds_writer = sh.writer_s;
       for (int k = 0; k < 3; ++k) report->zero_replacement[k] = repl[k];
     }
   } catch (const ScanError& e) {

@@ -39,13 +39,14 @@ class ScanOptions(C.Structure):
                 ("histories_per_projection", C.c_ulonglong), ("crop_nx", C.c_int), ("write_ascii", C.c_int), ("write_stacks", C.c_int),
                 ("output_folder", C.c_char_p), ("air_stack", C.c_char_p), ("air_sigma_y", C.c_double), ("air_sigma_x", C.c_double),
                 ("pixel_spacing_x", C.c_double), ("pixel_spacing_y", C.c_double),
-                ("shared_stacks", C.POINTER(C.c_void_p)), ("slice_of_projection", C.POINTER(C.c_int))]
+                ("shared_stacks", C.POINTER(C.c_void_p)), ("slice_of_projection", C.POINTER(C.c_int)), ("progress", C.c_int)]
 
 
 class ScanReport(C.Structure):
     """mcgpu_scan_report (include/mcgpu_amd.h)."""
     _fields_ = [("projections", C.c_int), ("histories_per_projection", C.c_ulonglong), ("seconds_total", C.c_double),
-                ("seconds_kernels", C.c_double), ("seconds_after_last_kernel", C.c_double), ("zero_replacement", C.c_float * 3)]
+                ("seconds_kernels", C.c_double), ("seconds_after_last_kernel", C.c_double), ("zero_replacement", C.c_float * 3),
+                ("seconds_writer", C.c_double)]
 
 
 class EngineError(RuntimeError):
@@ -381,7 +382,7 @@ class Context:
         _check(self.lib.mcgpu_run_scan(self.h, C.byref(o), C.byref(r)))
         return {"projections": r.projections, "histories_per_projection": r.histories_per_projection, "seconds_total": r.seconds_total,
                 "seconds_kernels": r.seconds_kernels, "seconds_after_last_kernel": r.seconds_after_last_kernel,
-                "zero_replacement": [float(v) for v in r.zero_replacement]}
+                "seconds_writer": r.seconds_writer, "zero_replacement": [float(v) for v in r.zero_replacement]}
 
     # -- dose tallies (SECTION DOSE DEPOSITION of the input file)
     def dose_info(self):

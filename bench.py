@@ -40,10 +40,11 @@ def build_workload(workdir: Path, n_vox: int, histories: int, n_proj: int, engin
     mats = cases.material_files()
     sim = pkg.simulation.MCSimulation(geo, mats, cases.spectrum_file(), n_histories=histories, n_projections=n_proj,
                                       angle_between_projections=360.0 / n_proj)
-    return sim.prepare_simulation(workdir, compress_geometry=False, engine=engine)
+    # geometry.vox (the reference's text format) + geometry.voxbin (binary sidecar the engine prefers: no 134 M-line parse)
+    return sim.prepare_simulation(workdir, compress_geometry=False, engine=engine, binary_sidecar=True)
 
 
-def cpu_baseline(ctx, seconds_budget: float = 12.0):
+def cpu_baseline(ctx, seconds_budget: float = 14.0):
     """The restated CPU oracle (oracle/mcgpu_oracle.c, LIBM math == reference arithmetic) on a bounded
     sample of the same workload, on this host's cores.  Reported, never the target."""
     import oracle_lib as ol
@@ -51,27 +52,58 @@ def cpu_baseline(ctx, seconds_budget: float = 12.0):
     T = parity.tables_from_context(ctx)
     cores = os.cpu_count() or 1
     hpt = 150
-    # calibrate: single-thread sample, then a short all-core sample, then the timed all-core sample
+    # one core first (per-core rate), then all cores in chunks of ~3 s until the budget is used
     t0 = time.perf_counter()
     cnt = ol.OracleCounters()
-    T.track(0, 42, 0, 200, hpt, ol.MATH_LIBM, n_threads=1, counters=cnt)
-    rate1 = 200 * hpt / (time.perf_counter() - t0)
-    nb_cal = cores * 8
-    t0 = time.perf_counter()
-    T.track(0, 42, 200, nb_cal, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
-    rate_all = nb_cal * hpt / (time.perf_counter() - t0)
-    nb = int(max(cores * 16, rate_all * seconds_budget / hpt))
-    t0 = time.perf_counter()
-    T.track(0, 42, 200 + nb_cal, nb, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
-    t2 = time.perf_counter() - t0
+    T.track(0, 42, 0, 400, hpt, ol.MATH_LIBM, n_threads=1, counters=cnt)
+    rate1 = 400 * hpt / (time.perf_counter() - t0)
+    batch0, done_batches, elapsed = 400, 0, 0.0
+    nb = cores * 16
+    while elapsed < seconds_budget:
+        t0 = time.perf_counter()
+        T.track(0, 42, batch0, nb, hpt, ol.MATH_LIBM, n_threads=cores, counters=cnt)
+        dt = time.perf_counter() - t0
+        batch0 += nb
+        if dt > 0.5:  # chunks too short to time OpenMP start-up fairly are warm-up only
+            done_batches += nb
+            elapsed += dt
+        nb = int(max(cores * 16, min(nb * 3.0 / max(dt, 1e-3), 4e6)))
     c = cnt.as_dict()
     h = float(c["histories"])
     per_hist = {k: round(c[k] / h, 4) for k in ("steps", "voxel_reads", "mfp_reads", "woodcock_reads", "compton", "rayleigh", "photo", "rng", "tally_calls", "tally_hits")}
     return {
-        "value": nb * hpt / t2, "unit": "histories/s", "cores": cores, "kind": "port",
-        "sample": f"{nb * hpt} histories of projection 0 of the same workload, OpenMP over RANECU batches (oracle/mcgpu_oracle.c, libm math)",
+        "value": done_batches * hpt / elapsed, "unit": "histories/s", "cores": cores, "kind": "port",
+        "sample": f"{done_batches * hpt} histories of projection 0 of the same workload in {elapsed:.1f} s, OpenMP over RANECU batches (oracle/mcgpu_oracle.c, libm math)",
         "per_core_value": rate1, "events_per_history": per_hist,
     }
+
+
+def pmc_traffic(kernel_ms: float):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC summary of this kernel (separate --pmc passes,
+    tools/pmc_collect.sh): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request,
+    so it is doubled (MI355X_MICROARCH.md, HBM section).  None when no summary is committed."""
+    f = ROOT / "profiles" / "pmc_summary_latest.json"
+    if not f.exists():
+        return None, None
+    d = json.loads(f.read_text())
+    try:
+        fetch, write = d["FETCH_SIZE"]["mean_per_dispatch"], d["WRITE_SIZE"]["mean_per_dispatch"]
+    except KeyError:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, d.get("_note", f.name)
+
+
+def end_to_end_scan(ctx, H, workdir, n=12):
+    """The pipelined scan driver (track -> finalize -> pinned copy -> writer thread) with the three MetaImage stacks
+    written to disk: per-projection wall time including output, reported beside the kernel-only figure."""
+    out = workdir / "scan_out"
+    out.mkdir(exist_ok=True)
+    rep = ctx.run_scan(mode="fast", first_projection=100, num_projections=n, histories=H, crop_nx=1024, write_stacks=True, output_folder=out,
+                       pixel_spacing=(0.776, 0.776))
+    for f in out.glob("projections_*.mha"):
+        f.unlink()
+    return {"projections": n, "ms_per_projection_with_stacks": rep["seconds_total"] / n * 1e3, "ms_per_projection_kernels": rep["seconds_kernels"] / n * 1e3,
+            "writer_ms_per_projection": rep["seconds_writer"] / n * 1e3, "drain_after_last_kernel_ms": rep["seconds_after_last_kernel"] * 1e3}
 
 
 def main():
@@ -83,6 +115,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=512)
     ap.add_argument("--projections", type=int, default=894)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the pipelined-scan measurement after the timed region")
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
 
@@ -109,7 +142,7 @@ def main():
     workdir = Path(args.workdir or os.path.join(tempfile.gettempdir(), f"mcgpu_bench_{args.voxels}_{args.projections}"))
     inp = workdir / "input.in"
     t_prep0 = time.perf_counter()
-    if rank == 0 and not (inp.exists() and (workdir / "geometry.vox").exists()):
+    if rank == 0 and not (inp.exists() and (workdir / "geometry.vox").exists() and (workdir / "geometry.voxbin").exists()):
         workdir.mkdir(parents=True, exist_ok=True)
         build_workload(workdir, args.voxels, H, args.projections, eng)
     if dist:
@@ -159,6 +192,7 @@ def main():
         value = total_hist / elapsed
         k_ms = float(np.mean(kernel_ms))
         achieved = ALGO_BYTES_PER_HISTORY * H / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(k_ms)
         out = {
             "metric": "photon histories/sec (512^3 vol, 894 proj)", "value": value, "unit": "histories/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -169,11 +203,13 @@ def main():
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
                        "volume_bytes": ctx.geti("volume_bytes_device"), "per_gpu_value": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "track_kernel<u8> (fast)", "kernel_ms_avg": k_ms,
-                         "algorithmic_bytes_per_history": ALGO_BYTES_PER_HISTORY},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "track_pool_kernel<u8> (fast)", "kernel_ms_avg": k_ms,
+                         "algorithmic_bytes_per_history": ALGO_BYTES_PER_HISTORY, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_HISTORY * H},
             "timing": {"prepare_inputs_s": t_prep, "load_and_upload_s": t_load},
             "check": {"detected_energy_units_last_projection": detected},
         }
+        if world == 1 and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end_scan(ctx, H, workdir)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx)
         else:

@@ -162,12 +162,14 @@ typedef struct mcgpu_scan_options {
    * scan (i = 0 .. num_projections-1) is written to slice slice_of_projection[i].  The caller finishes the stacks. */
   mcgpu_stack **shared_stacks;
   const int *slice_of_projection;
+  int progress;                                 /* print the reference's "<< Simulating Projection i of n >>" lines to stdout */
 } mcgpu_scan_options;
 typedef struct mcgpu_scan_report {
   int projections;
   unsigned long long histories_per_projection;
   double seconds_total, seconds_kernels, seconds_after_last_kernel;
   float zero_replacement[3];
+  double seconds_writer;                        /* busy time of the output thread (overlapped with tracking) */
 } mcgpu_scan_report;
 int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
 
