@@ -6,10 +6,13 @@
 //               512^3 Catphan604 -> 128 MiB (fits the 256 MiB Infinity Cache) instead of the
 //               reference's 1 GiB float2 array (MC-GPU_v1.3.cu:2135-2137).
 //   palette   : float2 {density, bits(compact material index)}  (staged in LDS when <=256 entries)
-//   bricks    : 4 bits per brick of (2^k)^3 voxels, <= 32768 bricks (16 KiB), LDS-resident: code c < 15 when all
-//               voxels of the brick share one palette entry (brick_palette[c], the 15 most frequent such entries),
-//               else 0xF ("mixed": read the voxel).  Most Woodcock steps land in homogeneous bricks (air, water
+//   bricks    : 4 bits per brick of (2^k)^3 voxels, <= 32768 bricks (16 KiB), LDS-resident: code c < 14 when all
+//               voxels of the brick share one palette entry (brick_palette[c], the 14 most frequent such entries),
+//               14 = EXTERIOR (background brick outside the bounding box of everything else), else 0xF ("mixed":
+//               read the voxel).  Most Woodcock steps land in homogeneous bricks (air, water
 //               body) and never touch the volume.
+//   mfp_tot   : per (energy bin, compact material) float2 {a_tot, b_tot}: 1.9 MB, L2-resident; the FAST flight step reads
+//               only this (virtual-or-real test); the kind of a real interaction is drawn later, in a batch
 //   mfp       : per (energy bin, compact material) one 32-byte record
 //               {a_tot, a_Co, a_Ra, b_tot | b_Co, b_Ra, pmax(bin+1), 0}  -- one aligned 32-B fetch where the
 //               reference reads 2 x float3 from two 7.2 MB tables plus pmax from a third (K.cu:268-269,336).
@@ -73,6 +76,9 @@ struct TrackArgs {
   int nx, ny, nz, nxy;
   float inv_vs[3];
   float bbox[3];
+  // FAST: region outside the object box (bricks coded kBrickExterior) is homogeneous background (palette slot 14)
+  int has_exterior, exterior_palette;
+  float objbox_lo[3], objbox_hi[3];
   float bbox_hi[3];  // FAST: largest coordinate still inside: <= bbox - EPS and mapping into the last voxel / brick
   LdsLayout lds;
   // energy grid and cross sections
@@ -80,6 +86,7 @@ struct TrackArgs {
   int num_values, nmat;
   const float* woodcock;  // float2[num_values]
   const float* mfp;       // 8 floats per (bin*nmat + mc)
+  const float* mfp_tot;   // float2 {a_tot, b_tot} per (bin*nmat + mc): the only cross section a flight step needs (FAST)
   const TrackCold* cold;
   int nbins;
   // pose of this projection (device-resident arrays of all projections, uploaded once)

@@ -54,6 +54,8 @@ struct DeviceModel {
   unsigned char* bricks = nullptr;
   int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, brick_bytes = 0, bricks_mixed = 0;
   int brick_palette[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int has_exterior = 0, bricks_exterior = 0;
+  float objbox_lo[3] = {0, 0, 0}, objbox_hi[3] = {0, 0, 0};
   int num_spectrum_bins = 0;
   LdsLayout lds;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
@@ -66,7 +68,7 @@ struct DeviceModel {
   int resident_fast = 0;  // workgroups per CU (occupancy query), 0 = not asked yet
   unsigned long long* stats = nullptr;  // kNumStats scheduler counters of the diagnostic build
   unsigned long long* work_counter = nullptr;  // history-id dispenser of the FAST kernel
-  float *woodcock = nullptr, *mfp = nullptr;
+  float *woodcock = nullptr, *mfp = nullptr, *mfp_tot = nullptr;
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
   float *fco = nullptr, *uico = nullptr, *fj0 = nullptr;
@@ -202,8 +204,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
           else if (first[b] != v) mixed[b] = 1;
         }
       }
-    // 4-bit codes: the 15 most frequent palette entries among homogeneous bricks get codes 0..14, every other
-    // brick (mixed, or a rarer homogeneous one) is 0xF = "read the voxel"
+    // 4-bit codes: the 14 most frequent palette entries among homogeneous bricks get codes 0..13, every other
+    // brick (mixed, or a rarer homogeneous one) is 0xF = "read the voxel"; code 14 = EXTERIOR (below)
     std::vector<long> homogeneous(256, 0);
     for (int b = 0; b < D.brick_count; ++b)
       if (!mixed[b] && first[b] >= 0) ++homogeneous[first[b]];
@@ -212,16 +214,53 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return homogeneous[a] > homogeneous[b]; });
     int code_of[256];
     for (int i = 0; i < 256; ++i) code_of[i] = 0xF;
-    for (int c = 0; c < 15; ++c) {
+    for (int c = 0; c < 14; ++c) {
       D.brick_palette[c] = 0;
       if (homogeneous[order[c]] > 0) { code_of[order[c]] = c; D.brick_palette[c] = order[c]; }
     }
-    D.brick_palette[15] = 0;
+    D.brick_palette[14] = D.brick_palette[15] = 0;
+    // Exterior: the object box is the bounding box (in bricks) of every brick that is not homogeneous background
+    // (background = the most frequent homogeneous entry).  Bricks outside it are all background: the FAST kernel crosses
+    // that region with one exact free-path sample instead of delta-tracking through it (track_pool.inc: exterior_hop).
+    D.has_exterior = 0;
+    {
+      const int bg = order[0];
+      int lo[3] = {D.brick_n[0], D.brick_n[1], D.brick_n[2]}, hi[3] = {-1, -1, -1};
+      for (int bz = 0; bz < D.brick_n[2]; ++bz)
+        for (int by = 0; by < D.brick_n[1]; ++by)
+          for (int bx = 0; bx < D.brick_n[0]; ++bx) {
+            const int b = (bz * D.brick_n[1] + by) * D.brick_n[0] + bx;
+            if (!mixed[b] && first[b] == bg) continue;
+            const int c3[3] = {bx, by, bz};
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c3[a]); hi[a] = std::max(hi[a], c3[a]); }
+          }
+      const bool disable = getenv("MCGPU_NO_EXTERIOR") != nullptr;
+      if (homogeneous[bg] > 0 && hi[0] >= 0 && !disable) {
+        long outside = 0;
+        for (int b = 0; b < D.brick_count; ++b) {
+          const int bx = b % D.brick_n[0], by = (b / D.brick_n[0]) % D.brick_n[1], bz = b / (D.brick_n[0] * D.brick_n[1]);
+          const bool out = bx < lo[0] || bx > hi[0] || by < lo[1] || by > hi[1] || bz < lo[2] || bz > hi[2];
+          if (out) { first[b] = -2; ++outside; }  // marks EXTERIOR for the encoder below
+        }
+        if (outside > 0) {
+          D.has_exterior = 1;
+          D.brick_palette[14] = bg;
+          const int nvx[3] = {nx, ny, nz};
+          for (int a = 0; a < 3; ++a) {
+            D.objbox_lo[a] = (float)(lo[a] << k) * H.voxels.voxel_size[a];
+            D.objbox_hi[a] = (float)std::min((hi[a] + 1) << k, nvx[a]) * H.voxels.voxel_size[a];
+          }
+        }
+      }
+    }
     D.brick_bytes = (D.brick_count + 1) / 2;
     std::vector<unsigned char> bricks(D.brick_bytes, 0xFF);
     D.bricks_mixed = 0;
+    D.bricks_exterior = 0;
     for (int b = 0; b < D.brick_count; ++b) {
-      const int code = (mixed[b] || first[b] < 0) ? 0xF : code_of[first[b]];
+      int code = 0xF;
+      if (first[b] == -2) { code = 14; ++D.bricks_exterior; }
+      else if (!mixed[b] && first[b] >= 0) code = code_of[first[b]];
       D.bricks_mixed += (code == 0xF);
       const int sh = (b & 1) * 4;
       bricks[b >> 1] = (unsigned char)((bricks[b >> 1] & ~(0xF << sh)) | (code << sh));
@@ -251,6 +290,11 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     }
   D.woodcock = D.put(wood);
   D.mfp = D.put(rec);
+  {
+    std::vector<float> tot(2 * (size_t)nv * nmat);
+    for (size_t k = 0; k < (size_t)nv * nmat; ++k) { tot[2 * k] = rec[8 * k]; tot[2 * k + 1] = rec[8 * k + 3]; }
+    D.mfp_tot = D.put(tot);
+  }
   std::vector<float> xco(kRayleighPoints * nmat), pco(xco), aco(xco), bco(xco);
   std::vector<unsigned char> itl(kRayleighPoints * nmat), itu(itl);
   std::vector<float> fco(kMaxShells * nmat, 0.f), uico(fco), fj0(fco);
@@ -359,12 +403,15 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   require((long long)A.nx * A.ny < (1LL << 24) && (long long)H.voxels.count() < (1LL << 31), -2,
           "!!ERROR!! voxel grid too large for the 32-bit voxel index of the kernel");
   A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat;
-  A.woodcock = D.woodcock; A.mfp = D.mfp;
+  A.woodcock = D.woodcock; A.mfp = D.mfp; A.mfp_tot = D.mfp_tot;
   A.cold = D.cold;
   A.nbins = H.spectrum.num_bins;
   A.src = D.src_all + p; A.det = D.det_all + p;
   A.stream_key = (unsigned)p;
   A.dose_flags = D.dose_flags;
+  A.has_exterior = (D.vol_kind == kVolU8) ? D.has_exterior : 0;
+  for (int k = 0; k < 3; ++k) { A.objbox_lo[k] = D.objbox_lo[k]; A.objbox_hi[k] = D.objbox_hi[k]; }
+  A.exterior_palette = D.brick_palette[14];
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 32);
@@ -492,6 +539,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "brick_shift") *value = ctx->dev.brick_shift;
   else if (k == "brick_count") *value = ctx->dev.brick_count;
   else if (k == "bricks_mixed") *value = ctx->dev.bricks_mixed;
+  else if (k == "bricks_exterior") *value = ctx->dev.bricks_exterior;
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
   else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots;

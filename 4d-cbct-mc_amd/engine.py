@@ -279,10 +279,10 @@ class Context:
 
     def scheduler_stats(self, reset: bool = True) -> dict:
         """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""
-        out = (C.c_ulonglong * 12)()
-        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 12, int(reset)))
+        out = (C.c_ulonglong * 16)()
+        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 16, int(reset)))
         names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
-                 "scheduling_points", "take_rounds", "take_lanes", "drain_points")
+                 "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

@@ -17,7 +17,7 @@ with eng.create(inp, device=0) as ctx:
             os.environ[k] = v
         ctx.run_projection(0, n, mode="fast", seed=42)  # warm
         _, secs, _ = ctx.run_projection(0, n, mode="fast", seed=42)
-        img, _, done = ctx.run_projection(0, n, mode="stats", seed=42)
+        img, secs_stats, done = ctx.run_projection(0, n, mode="stats", seed=42)
         s = ctx.scheduler_stats()
         it = max(s["iterations"], 1)
         print(json.dumps({"cfg": cfg, "Mhist_per_s": round(done / secs / 1e6, 1), "iter_per_hist": round(it / done, 4),
@@ -28,4 +28,6 @@ with eng.create(inp, device=0) as ctx:
                           "sched_points_per_hist": round(s["scheduling_points"] / done, 4),
                           "take": [round(s["take_lanes"] / max(s["take_rounds"], 1), 1), round(s["take_rounds"] / done, 5)],
                           "drain_frac": round(s["drain_points"] / max(s["scheduling_points"], 1), 3),
+                          "cycles_per_hist": {k[7:]: round(s[k] / done, 1) for k in ("cycles_flight", "cycles_compton", "cycles_rayleigh", "cycles_new")},
+                          "wave_cycles_per_hist_total(100MHz ticks?)": round(secs_stats * 1e8 * 6144 / done, 1),
                           "blocks_per_cu": ctx.geti("blocks_per_cu"), "lds": ctx.geti("lds_bytes_fast")}))
