@@ -27,7 +27,8 @@
 namespace mcgpu {
 
 enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
-constexpr int kTrackBlockThreads = 512;   // 8 waves per workgroup
+constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
+constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kSlotWords = 13;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kNumStats = 16;             // scheduler counters of the diagnostic build
@@ -42,7 +43,7 @@ struct LdsLayout {
   int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
   int brick;                 // u8[brick_bytes]
   int dose_mat;              // u64[25][2]: per-workgroup material-dose accumulators, flushed at kernel end
-  int slots;                 // u32[kSlotWords][kTrackBlockThreads] (FAST kernel only)
+  int slots;                 // u32[kSlotWords][kPoolBlockThreads] (FAST kernel only)
   int total;                 // bytes
 };
 

@@ -341,7 +341,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.brick = take(D.vol_kind == kVolU8 ? D.brick_bytes : 0, 16);
     Y.dose_mat = take(2 * kMaxMaterials * 8, 16);
     Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
-    take(kSlotWords * kTrackBlockThreads * 4, 16);
+    take(kSlotWords * kPoolBlockThreads * 4, 16);
     Y.total = (off + 15) / 16 * 16;
   }
   D.num_spectrum_bins = H.spectrum.num_bins;
@@ -409,16 +409,16 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.src = D.src_all + p; A.det = D.det_all + p;
   A.stream_key = (unsigned)p;
   A.dose_flags = D.dose_flags;
-  A.has_exterior = (D.vol_kind == kVolU8) ? D.has_exterior : 0;
   for (int k = 0; k < 3; ++k) { A.objbox_lo[k] = D.objbox_lo[k]; A.objbox_hi[k] = D.objbox_hi[k]; }
   A.exterior_palette = D.brick_palette[14];
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 32);
+  A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? env_int("MCGPU_EXTERIOR_MODE", 3) : 0;  // bit 0: hop during flight, bit 1: hop at the source
+  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 48);
   A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 8);
-  A.thresh_new = env_int("MCGPU_THRESH_NEW", 32);
+  A.thresh_new = env_int("MCGPU_THRESH_NEW", 48);
   A.flyable_low = std::max(1, env_int("MCGPU_FLYABLE_LOW", 16));
-  A.swap_batch = std::max(1, env_int("MCGPU_SWAP_BATCH", 8));
+  A.swap_batch = std::max(1, env_int("MCGPU_SWAP_BATCH", 16));
   return A;
 }
 
@@ -643,7 +643,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         D.resident_fast = v ? atoi(v) : occupancy_track_fast(A);
         if (D.resident_fast <= 0) D.resident_fast = 1;
       }
-      const unsigned long long want = (count + kTrackBlockThreads - 1) / kTrackBlockThreads;
+      const unsigned long long want = (count + kPoolBlockThreads - 1) / kPoolBlockThreads;
       const unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
       if (!D.work_counter) D.work_counter = D.put(std::vector<unsigned long long>(2, 0ULL));
       HIP_TRY(hipMemsetAsync(D.work_counter, 0, 8, stream));
