@@ -65,6 +65,11 @@ struct TrackCold {
   unsigned long long* dose_materials;  // ulonglong2 per material number (25 entries); null = tally off
   int dose_roi[6];                     // 0-based inclusive xmin,xmax,ymin,ymax,zmin,zmax
   int material_of_compact[25];         // material number - 1 of compact material index mc
+  // FAST kernel, scheduling points only (kept out of the launch arguments = out of the SGPR file)
+  float objbox_lo[3], objbox_hi[3];    // object box [cm]: outside it every brick is kBrickExterior
+  // parked histories per wave64 that trigger a batched service of that kind; service everything well populated when
+  // fewer lanes than `flyable_low` can fly; stop for a scheduling point once `swap_batch` more lanes have parked
+  int thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch;
 };
 
 struct TrackArgs {
@@ -77,9 +82,9 @@ struct TrackArgs {
   int nx, ny, nz, nxy;
   float inv_vs[3];
   float bbox[3];
-  // FAST: region outside the object box (bricks coded kBrickExterior) is homogeneous background (palette slot 14)
-  int has_exterior, exterior_palette;
-  float objbox_lo[3], objbox_hi[3];
+  // FAST: region outside the object box (bricks coded kBrickExterior) is homogeneous background (palette slot 14);
+  // bit 0: hop during flight, bit 1: hop at the source (the box itself is in TrackCold)
+  int has_exterior;
   float bbox_hi[3];  // FAST: largest coordinate still inside: <= bbox - EPS and mapping into the last voxel / brick
   LdsLayout lds;
   // energy grid and cross sections
@@ -99,11 +104,8 @@ struct TrackArgs {
   int seed, hpt;
   unsigned long long first, count;
   unsigned int stream_key;  // FAST: projection index mixed into the Philox key
-  // parked histories per wave64 that trigger a batched service of that kind
+  // COMPAT kernel: parked lanes per wave64 that trigger a batched service of that kind
   int thresh_compton, thresh_rayleigh, thresh_new;
-  // FAST kernel: service everything pending when fewer lanes than `flyable_low` can fly; bring parked/flying
-  // histories in/out of the LDS slots once `swap_batch` lanes have parked
-  int flyable_low, swap_batch;
   int dose_flags;             // bit 0: material dose tally, bit 1: voxel dose tally (TrackCold holds the buffers)
   unsigned long long* stats;  // diagnostic build only (kNumStats counters), else null
   unsigned long long* work_counter;  // FAST: next unassigned history offset (zeroed before each launch)

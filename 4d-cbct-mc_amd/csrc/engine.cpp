@@ -59,6 +59,7 @@ struct DeviceModel {
   int num_spectrum_bins = 0;
   LdsLayout lds;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
+  TrackCold cold_host;            // its host image (re-uploaded when a tuning knob changes)
   unsigned long long* dose_voxels = nullptr;     // ulonglong2 per ROI voxel (null: tally off)
   unsigned long long* dose_materials = nullptr;  // ulonglong2 x 25 (null: tally off)
   size_t dose_roi_voxels = 0;
@@ -370,6 +371,9 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     for (int k = 0; k < 6; ++k) cold.dose_roi[k] = cfg.dose_roi[k];
     for (int m = 0; m < kMaxMaterials; ++m)
       if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
+    for (int k = 0; k < 3; ++k) { cold.objbox_lo[k] = D.objbox_lo[k]; cold.objbox_hi[k] = D.objbox_hi[k]; }
+    cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = -1;  // set at launch
+    D.cold_host = cold;
     D.cold = D.put(std::vector<TrackCold>(1, cold));
     D.src_all = D.put(H.source);
     D.det_all = D.put(H.detector);
@@ -409,16 +413,14 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.src = D.src_all + p; A.det = D.det_all + p;
   A.stream_key = (unsigned)p;
   A.dose_flags = D.dose_flags;
-  for (int k = 0; k < 3; ++k) { A.objbox_lo[k] = D.objbox_lo[k]; A.objbox_hi[k] = D.objbox_hi[k]; }
-  A.exterior_palette = D.brick_palette[14];
+
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? env_int("MCGPU_EXTERIOR_MODE", 3) : 0;  // bit 0: hop during flight, bit 1: hop at the source
-  A.thresh_compton = env_int("MCGPU_THRESH_COMPTON", 48);
-  A.thresh_rayleigh = env_int("MCGPU_THRESH_RAYLEIGH", 8);
-  A.thresh_new = env_int("MCGPU_THRESH_NEW", 48);
-  A.flyable_low = std::max(1, env_int("MCGPU_FLYABLE_LOW", 16));
-  A.swap_batch = std::max(1, env_int("MCGPU_SWAP_BATCH", 16));
+  // batching thresholds of the COMPAT kernel (one history per lane)
+  A.thresh_compton = env_int("MCGPU_COMPAT_THRESH_COMPTON", 20);
+  A.thresh_rayleigh = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", 6);
+  A.thresh_new = env_int("MCGPU_COMPAT_THRESH_NEW", 24);
   return A;
 }
 
@@ -645,6 +647,18 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       }
       const unsigned long long want = (count + kPoolBlockThreads - 1) / kPoolBlockThreads;
       const unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
+      {  // FAST scheduling knobs live in TrackCold; the environment may change them between launches (tuning sweeps)
+        auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+        TrackCold& ch = D.cold_host;
+        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", 48), env_int("MCGPU_THRESH_RAYLEIGH", 8), env_int("MCGPU_THRESH_NEW", 48),
+                              std::max(1, env_int("MCGPU_FLYABLE_LOW", 16)), std::max(1, env_int("MCGPU_SWAP_BATCH", 16))};
+        if (ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
+            ch.swap_batch != want5[4]) {
+          ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];
+          HIP_TRY(hipStreamSynchronize(stream));
+          HIP_TRY(hipMemcpy(D.cold, &ch, sizeof ch, hipMemcpyHostToDevice));
+        }
+      }
       if (!D.work_counter) D.work_counter = D.put(std::vector<unsigned long long>(2, 0ULL));
       HIP_TRY(hipMemsetAsync(D.work_counter, 0, 8, stream));
       A.work_counter = D.work_counter;
