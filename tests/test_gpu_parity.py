@@ -113,3 +113,46 @@ def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
         assert frac3 < 0.01, f"{name}: {frac3:.4f} of {mask.sum()} pixels beyond 3 sigma (expect ~0.003)"
         assert np.abs(z[mask]).max() < 6.0
         assert abs(z[mask].mean()) < 0.25
+
+
+def test_fast_image_is_independent_of_the_schedule(gpu_engine, case_dir, monkeypatch):
+    """Per-history RNG streams + integer tallies: batching thresholds, exchange cadence and the exterior hop's timing must not
+    change a single tally word (this is also what makes the multi-GPU sum exact).  Catches histories dropped or duplicated by
+    the wave scheduler."""
+    with gpu_engine.create(case_dir("catphan64_ct"), device=0) as ctx:
+        n = 1_500_000
+        ref = [ctx.run_projection(p, n, mode="fast", seed=11)[0] for p in (0, 2)]
+        for knobs in ({"MCGPU_THRESH_COMPTON": "1", "MCGPU_THRESH_RAYLEIGH": "1", "MCGPU_THRESH_NEW": "1", "MCGPU_SWAP_BATCH": "1"},
+                      {"MCGPU_THRESH_COMPTON": "64", "MCGPU_THRESH_RAYLEIGH": "64", "MCGPU_THRESH_NEW": "64", "MCGPU_FLYABLE_LOW": "1", "MCGPU_SWAP_BATCH": "40"},
+                      {"MCGPU_THRESH_COMPTON": "7", "MCGPU_THRESH_NEW": "50", "MCGPU_FLYABLE_LOW": "40", "MCGPU_SWAP_BATCH": "3"}):
+            for k, v in knobs.items():
+                monkeypatch.setenv(k, v)
+            for i, p in enumerate((0, 2)):
+                for rep in range(2):
+                    img = ctx.run_projection(p, n, mode="fast", seed=11)[0]
+                    assert np.array_equal(img, ref[i]), (knobs, p, rep)
+            for k in knobs:
+                monkeypatch.delenv(k)
+
+
+def test_fast_exterior_hop_is_statistically_equivalent_to_delta_tracking(gpu_engine, case_dir, monkeypatch):
+    """The analytic crossing of the homogeneous exterior (track_pool.inc: exterior_hop) against plain Woodcock tracking
+    everywhere (MCGPU_NO_EXTERIOR): two independent estimates of the same images."""
+    n = 30_000_000
+    with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
+        assert ctx.geti("bricks_exterior") > 0
+        hop, _, _ = ctx.run_projection(0, n, mode="fast", seed=5)
+    monkeypatch.setenv("MCGPU_NO_EXTERIOR", "1")
+    with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
+        assert ctx.geti("bricks_exterior") == 0
+        plain, _, _ = ctx.run_projection(0, n, mode="fast", seed=6)
+    for k in range(4):
+        a, b = hop[k].sum() / n, plain[k].sum() / n
+        counts = plain[k].sum() / 6.0e6
+        assert abs(a / b - 1.0) < 4.0 * np.sqrt(2 * 1.6 / counts) + 1e-4, (k, a, b)
+    nz, nx = hop.shape[1:]
+    g = hop[:, : nz // 3 * 3, : nx // 3 * 3].reshape(4, nz // 3, 3, nx // 3, 3).sum(axis=(2, 4))
+    c = plain[:, : nz // 3 * 3, : nx // 3 * 3].reshape(4, nz // 3, 3, nx // 3, 3).sum(axis=(2, 4))
+    z, mask = parity.poisson_z(g, n, c, n)
+    assert mask.sum() > 500
+    assert np.mean(np.abs(z[mask]) > 3.0) < 0.01 and np.abs(z[mask]).max() < 6.0 and abs(z[mask].mean()) < 0.1
