@@ -119,6 +119,12 @@ def main():
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner from C stdio on
+    # its first collective), so everything else is sent to stderr and the line goes to the original descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,9 +135,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the latter: exercise the collective path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import cases
@@ -153,7 +160,10 @@ def main():
     t_load = time.perf_counter() - t_load0
 
     nz, nx = ctx.detector_shape
-    image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
+    # two tally buffers: the RCCL reduce of projection i (on the communicator's own stream) overlaps the tracking of
+    # projection i + 1; a buffer is cleared again only after its reduce has been waited for
+    images = [torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda") for _ in range(2 if dist else 1)]
+    pending = [None] * len(images)
     stream = torch.cuda.current_stream().cuda_stream
     nproj = ctx.num_projections
     seed = ctx.geti("seed")
@@ -161,22 +171,36 @@ def main():
 
     def step(i, timed):
         p = (i * 149) % nproj  # spread the sampled projections over the arc
+        b = i % len(images)
+        image = images[b]
+        if pending[b] is not None:
+            pending[b].wait()  # stream-level: the clear below is ordered behind that reduce
+            pending[b] = None
         ctx.clear(image.data_ptr(), stream)
         # disjoint history ids per rank: [rank*H, (rank+1)*H)
         ctx.launch(p, image.data_ptr(), H, mode="fast", seed=seed, first=rank * H, stream=stream)
-        if timed:
-            kernel_ms.append(ctx.last_kernel_ms())
         if dist:
-            dist.reduce(image, dst=0, op=dist.ReduceOp.SUM)  # per-projection detector tally -> rank 0 (RCCL over xGMI)
+            # per-projection detector tally -> rank 0 (RCCL over xGMI; the reference's MPI_Reduce, H.cu:1019)
+            pending[b] = dist.reduce(image, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        if timed:
+            kernel_ms.append(ctx.last_kernel_ms())  # waits for this launch only
+
+    def drain():
+        for b in range(len(images)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for i in range(args.warmup):
         step(i, False)
+    drain()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, True)
+    drain()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,7 +209,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    detected = int(image.sum().item()) if rank == 0 else 0
+    detected = int(images[(args.warmup + args.steps - 1) % len(images)].sum().item()) if rank == 0 else 0
 
     if rank == 0:
         total_hist = float(H) * world * args.steps
@@ -199,7 +223,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"catphan604_{args.voxels}cube_1mm_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
                        "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
-                       "parallelism": f"history-sharded x{world}, RCCL sum-reduce of the detector tally per projection",
+                       "parallelism": f"history-sharded x{world}, RCCL sum-reduce of the detector tally per projection (overlapped with the next projection)",
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
                        "volume_bytes": ctx.geti("volume_bytes_device"), "per_gpu_value": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -214,7 +238,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ctx)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist:
         dist.barrier()
