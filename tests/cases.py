@@ -58,6 +58,22 @@ def _slab_nonsquare():
     return g
 
 
+def _graded(n_levels):
+    """Tissue-like block whose densities take `n_levels` distinct values: > 256 (material, density) pairs make the engine
+    store the volume as 16-bit palette indices, > 65536 as raw float2 voxels (device_model.hpp)."""
+    def make():
+        shape = (48, 44, 42)
+        rng = np.random.default_rng(n_levels)
+        g = geometry.MCBoxGeometry(shape=shape, image_spacing=(6.0, 6.0, 6.0), material="h2o")
+        levels = np.round(np.linspace(0.2, 1.9, n_levels), 6).astype(np.float32)
+        g.densities[:] = levels[rng.permutation(int(np.prod(shape))) % n_levels].reshape(shape)  # every level occurs
+        g.materials[10:30, 12:32, 8:34] = materials.material_number("bone_050")
+        g.materials[:4] = materials.material_number("air")
+        g.densities[:4] = np.float32(0.0013)
+        return g
+    return make
+
+
 SMALL_DET = dict(n_detector_pixels=(231, 96), detector_size=(717.024, 297.984))
 CASES = {
     "air": (_air, dict(n_projections=1, n_histories=300_000, **SMALL_DET)),
@@ -65,6 +81,8 @@ CASES = {
     "catphan64": (_catphan_small, dict(n_projections=1, n_histories=300_000, **SMALL_DET)),
     "catphan64_ct": (_catphan_small, dict(n_projections=4, angle_between_projections=90.0, n_histories=60_000, **SMALL_DET)),
     "slab_angles": (_slab_nonsquare, dict(projection_angles=[270.0, 300.5, 45.25], n_histories=60_000, **SMALL_DET)),
+    "graded_u16": (_graded(3000), dict(n_projections=2, angle_between_projections=77.0, n_histories=60_000, **SMALL_DET)),
+    "graded_raw": (_graded(80000), dict(n_projections=1, n_histories=60_000, **SMALL_DET)),
     # both dose tallies on (the reference template keeps them off): ROI in 1-based inclusive voxel indices; two
     # projections, because the dose arrays accumulate over the scan
     "catphan64_dose": (_catphan_small, dict(n_projections=2, angle_between_projections=90.0, n_histories=60_000,

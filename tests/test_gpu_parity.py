@@ -12,7 +12,8 @@ import parity
 
 pytestmark = pytest.mark.gpu
 
-CASE_BATCHES = [("air", 256), ("water", 512), ("catphan64", 512), ("catphan64_ct", 256), ("slab_angles", 256)]
+CASE_BATCHES = [("air", 256), ("water", 512), ("catphan64", 512), ("catphan64_ct", 256), ("slab_angles", 256), ("graded_u16", 256),
+                ("graded_raw", 256)]
 
 
 @pytest.fixture(scope="module")
@@ -84,7 +85,16 @@ def test_fast_history_sharding_and_determinism(gpu_engine, case_dir):
         assert not np.array_equal(whole, other)
 
 
-@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles"])
+def test_volume_storage_kinds_are_exercised(gpu_engine, case_dir):
+    """u8 palette / u16 palette / raw float2 voxels (device_model.hpp): the graded cases reach the two wider kinds."""
+    kinds = {}
+    for name in ("catphan64", "graded_u16", "graded_raw"):
+        with gpu_engine.create(case_dir(name), device=0) as ctx:
+            kinds[name] = ctx.geti("volume_kind")
+    assert kinds == {"catphan64": 0, "graded_u16": 1, "graded_raw": 2}
+
+
+@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw"])
 def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
     """FAST vs oracle (LIBM math = the reference's own arithmetic): every class image, per pixel."""
     with gpu_engine.create(case_dir(name), device=0) as ctx:
