@@ -37,7 +37,7 @@ constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
 // Byte offsets of the kernel's dynamic LDS image (track_common.inc: stage_tables).  Sized for the materials and
 // palette entries actually in use so that three 512-thread workgroups fit one CU's 160 KiB.
 struct LdsLayout {
-  int fco, uico, fj0;        // float[kMaxShells * nmat] each, index shell * nmat + material
+  int shells;                // float4 {U, J, f, 0}[shell_rows * nmat], index shell * nmat + material
   int nosc;                  // int[nmat]
   int espc, cutoff, alias;   // float[nbins + 1], float[nbins + 1], short[nbins + 1]
   int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
@@ -90,6 +90,7 @@ struct TrackArgs {
   // energy grid and cross sections
   float e0, ide;
   int num_values, nmat;
+  int shell_rows;  // largest number of Compton shells among the materials in use
   const float* woodcock;  // float2[num_values]
   const float* mfp;       // 8 floats per (bin*nmat + mc)
   const float* mfp_tot;   // float2 {a_tot, b_tot} per (bin*nmat + mc): the only cross section a flight step needs (FAST)
