@@ -37,8 +37,8 @@ constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
 // Byte offsets of the kernel's dynamic LDS image (track_common.inc: stage_tables).  Sized for the materials and
 // palette entries actually in use so that three 512-thread workgroups fit one CU's 160 KiB.
 struct LdsLayout {
-  int shells;                // float4 {U, J, f, 0}[shell_rows * nmat], index shell * nmat + material
-  int nosc;                  // int[nmat]
+  int shells;                // float4 {U, J, f, 0}[sum of shells over the materials], material after material
+  int nosc;                  // int[2 * nmat]: number of shells, then first shell, per material
   int espc, cutoff, alias;   // float[nbins + 1], float[nbins + 1], short[nbins + 1]
   int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
   int brick;                 // u8[brick_bytes]
@@ -65,6 +65,7 @@ struct TrackCold {
   unsigned long long* dose_materials;  // ulonglong2 per material number (25 entries); null = tally off
   int dose_roi[6];                     // 0-based inclusive xmin,xmax,ymin,ymax,zmin,zmax
   int material_of_compact[25];         // material number - 1 of compact material index mc
+  int shell_first[25];                 // index of the first Compton shell of compact material mc in the LDS shell table
   // FAST kernel, scheduling points only (kept out of the launch arguments = out of the SGPR file)
   float objbox_lo[3], objbox_hi[3];    // object box [cm]: outside it every brick is kBrickExterior
   // parked histories per wave64 that trigger a batched service of that kind; service everything well populated when
@@ -90,7 +91,6 @@ struct TrackArgs {
   // energy grid and cross sections
   float e0, ide;
   int num_values, nmat;
-  int shell_rows;  // largest number of Compton shells among the materials in use
   const float* woodcock;  // float2[num_values]
   const float* mfp;       // 8 floats per (bin*nmat + mc)
   const float* mfp_tot;   // float2 {a_tot, b_tot} per (bin*nmat + mc): the only cross section a flight step needs (FAST)

@@ -56,7 +56,8 @@ struct DeviceModel {
   int brick_palette[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int has_exterior = 0, bricks_exterior = 0;
   float objbox_lo[3] = {0, 0, 0}, objbox_hi[3] = {0, 0, 0};
-  int num_spectrum_bins = 0, shell_rows = 1;
+  int num_spectrum_bins = 0;
+  int shell_first[kMaxMaterials] = {0};
   LdsLayout lds;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
   TrackCold cold_host;            // its host image (re-uploaded when a tuning knob changes)
@@ -331,11 +332,11 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     int off = 0;
     auto take = [&](int bytes, int align) { off = (off + align - 1) / align * align; const int at = off; off += bytes; return at; };
     const int ns = std::min(H.spectrum.num_bins + 1, kMaxSpectrumBins) + 1;
-    D.shell_rows = 1;
+    int total_shells = 0;
     for (int m = 0; m < kMaxMaterials; ++m)
-      if (D.compact_of[m] >= 0) D.shell_rows = std::max(D.shell_rows, std::min(H.mat.noscco[m], kMaxShells));
-    Y.shells = take(D.shell_rows * nmat * 16, 16);
-    Y.nosc = take(std::max(nmat, 1) * 4, 16);
+      if (D.compact_of[m] >= 0) { D.shell_first[D.compact_of[m]] = total_shells; total_shells += std::min(H.mat.noscco[m], kMaxShells); }
+    Y.shells = take(std::max(total_shells, 1) * 16, 16);
+    Y.nosc = take(std::max(nmat, 1) * 8, 16);
     Y.espc = take(ns * 4, 16);
     Y.cutoff = take(ns * 4, 16);
     Y.alias = take(ns * 2, 16);
@@ -372,6 +373,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     for (int k = 0; k < 6; ++k) cold.dose_roi[k] = cfg.dose_roi[k];
     for (int m = 0; m < kMaxMaterials; ++m)
       if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
+    for (int m = 0; m < kMaxMaterials; ++m) cold.shell_first[m] = D.shell_first[m];
     for (int k = 0; k < 3; ++k) { cold.objbox_lo[k] = D.objbox_lo[k]; cold.objbox_hi[k] = D.objbox_hi[k]; }
     cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = -1;  // set at launch
     D.cold_host = cold;
@@ -407,7 +409,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   }
   require((long long)A.nx * A.ny < (1LL << 24) && (long long)H.voxels.count() < (1LL << 31), -2,
           "!!ERROR!! voxel grid too large for the 32-bit voxel index of the kernel");
-  A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat; A.shell_rows = D.shell_rows;
+  A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat;
   A.woodcock = D.woodcock; A.mfp = D.mfp; A.mfp_tot = D.mfp_tot;
   A.cold = D.cold;
   A.nbins = H.spectrum.num_bins;
