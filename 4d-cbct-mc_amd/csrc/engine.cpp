@@ -70,6 +70,7 @@ struct DeviceModel {
   int resident_fast = 0;  // workgroups per CU (occupancy query), 0 = not asked yet
   unsigned long long* stats = nullptr;  // kNumStats scheduler counters of the diagnostic build
   unsigned long long* work_counter = nullptr;  // history-id dispenser of the FAST kernel
+  unsigned long long* scratch_image = nullptr;  // device tally of mcgpu_run_projection (allocated on first use)
   float *woodcock = nullptr, *mfp = nullptr, *mfp_tot = nullptr;
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
@@ -721,8 +722,8 @@ int mcgpu_run_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned lon
   require(ctx && ctx->has_device && image_host, -1, "!!ERROR!! mcgpu_run_projection: bad argument");
   HIP_TRY(hipSetDevice(ctx->dev.device_id));
   const size_t bytes = (size_t)32 * ctx->host.detector[0].total_pixels;
-  void* img = nullptr;
-  HIP_TRY(hipMalloc(&img, bytes));
+  if (!ctx->dev.scratch_image) ctx->dev.scratch_image = (unsigned long long*)ctx->dev.put(std::vector<unsigned char>(bytes, 0));  // kept for the next call
+  void* img = ctx->dev.scratch_image;
   int rc = 0;
   try {
     HIP_TRY(hipMemset(img, 0, bytes));
@@ -735,10 +736,8 @@ int mcgpu_run_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned lon
       if (histories_done) *histories_done = (mode == MCGPU_MODE_COMPAT) ? count * (unsigned long long)hpt : count;
     }
   } catch (...) {
-    (void)hipFree(img);
     throw;
   }
-  (void)hipFree(img);
   return rc;
   ABI_END
 }

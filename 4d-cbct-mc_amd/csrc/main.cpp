@@ -6,6 +6,8 @@
 //   --mode fast|compat   kernel personality (default fast)
 //   --gpus N             history-shard every projection over N devices of this node (default 1);
 //                        per-device tallies are summed on the host (integers: order-independent)
+//   --devices a,b,...    the same with an explicit device list (a device may appear twice: used by the tests to run the
+//                        sharded path on a single-GPU box)
 //   --no-output          skip the ASCII projection files (timing runs, or stacks only)
 //   --stacks             also write projections_{total,unscattered,scattered}.mha next to the projection files
 //                        (what cbctmc/mc/simulation.py:235-277 builds from the ASCII files afterwards)
@@ -35,7 +37,16 @@ int main(int argc, char** argv) {
   bool write_out = true, stacks = false;
   int crop = -1;
   const char* air = nullptr;
+  std::vector<int> device_list;
   for (int i = 2; i < argc; ++i) {
+    if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+      for (const char* s = argv[++i]; *s;) {
+        device_list.push_back(atoi(s));
+        while (*s && *s != ',') ++s;
+        if (*s == ',') ++s;
+      }
+      continue;
+    }
     if (!strcmp(argv[i], "--stacks")) { stacks = true; continue; }
     if (!strcmp(argv[i], "--crop") && i + 1 < argc) { crop = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--air") && i + 1 < argc) { air = argv[++i]; continue; }
@@ -43,6 +54,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--no-output")) write_out = false;
   }
+  if (!device_list.empty()) ngpu = (int)device_list.size();
   if (ngpu < 1) ngpu = 1;
   const double t_begin = now_s();
   printf("\n     *** MC CBCT projection engine for AMD MI355X (MC-GPU v1.3 file contract) ***\n\n    -- INITIALIZATION phase:\n");
@@ -51,8 +63,8 @@ int main(int argc, char** argv) {
   long long gpu_id = 0;
   for (int g = 0; g < ngpu; ++g) {
     // single GPU: the input file's GPU number; several: devices 0..N-1
-    int dev = g;
-    if (ngpu == 1) {
+    int dev = device_list.empty() ? g : device_list[g];
+    if (ngpu == 1 && device_list.empty()) {
       mcgpu_ctx* probe = nullptr;
       if (mcgpu_create(argv[1], -1, &probe) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 254; }
       mcgpu_config_i64(probe, "gpu_id", &gpu_id);
@@ -151,8 +163,20 @@ int main(int argc, char** argv) {
     for (auto& t : th) t.join();
     for (int g = 0; g < ngpu; ++g)
       if (rc[g]) { printf("\n\n   %s\n\n", err[g].c_str()); return 253; }
-    for (int g = 1; g < ngpu; ++g)
-      for (size_t i = 0; i < words; ++i) img[0][i] += img[g][i];
+    {  // integer sum of the per-device tallies (the reference's MPI_Reduce, MC-GPU_v1.3.cu:1019), banded over host threads
+      const int T = 8;
+      std::vector<std::thread> add;
+      for (int t = 0; t < T; ++t)
+        add.emplace_back([&, t]() {
+          const size_t lo = words * t / T, hi = words * (t + 1) / T;
+          for (int g = 1; g < ngpu; ++g) {
+            const uint64_t* src = img[g].data();
+            uint64_t* dst = img[0].data();
+            for (size_t i = lo; i < hi; ++i) dst[i] += src[i];
+          }
+        });
+      for (auto& t : add) t.join();
+    }
     const double dt = now_s() - t0;
     t_mc += dt;
     printf("          *** IMAGE TALLY PERFORMANCE REPORT ***\n              CT projection %d of %d\n              Simulated x rays:    %llu\n"

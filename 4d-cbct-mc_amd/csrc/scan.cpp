@@ -116,6 +116,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       for (int k = 0; k < 3; ++k) ABI_OK(mcgpu_stack_create((folder + "/" + kNames[k]).c_str(), cx, (int)nz, count, sx, sy, &stacks[k]));
     }
 
+    std::vector<float> kms(count, 0.f);  // kernel time per projection (written before the projection is queued)
     // ---- writer thread: consumes buffers in order
     writer = std::thread([&]() {
       for (int i = 0; i < count; ++i) {
@@ -139,7 +140,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
             wrc = mcgpu_stack_write_slice(opt->shared_stacks[k], opt->slice_of_projection[i], planes_host[b] + (size_t)k * plane);
         else if (opt->write_stacks)
           for (int k = 0; k < 3 && wrc == 0; ++k) wrc = mcgpu_stack_append(stacks[k], planes_host[b] + (size_t)k * plane);
-        if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, 0.0, nullptr);
+        if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, (double)kms[i] * 1e-3, nullptr);
         std::lock_guard<std::mutex> lk(sh.mu);
         sh.writer_s += now_s() - tw0;
         if (wrc != 0) { sh.error = mcgpu_last_error(); sh.abort = true; }
@@ -155,7 +156,6 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     int cur_seed = (int)seed;
     if (mode == MCGPU_MODE_COMPAT)
       for (int p = 0; p < first; ++p) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
-    std::vector<float> kms(count, 0.f);
     for (int i = 0; i < count; ++i) {
       const int b = i & 1, p = first + i;
       {  // buffer b is free once projection i-2 has been written
@@ -172,12 +172,6 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       ABI_OK(mcgpu_finalize_projection(ctx, image_dev, total, cx, planes_dev[b], 1, stream));
       HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipEventRecord(done[b], stream));
-      {
-        std::lock_guard<std::mutex> lk(sh.mu);
-        sh.queued = i + 1;
-        sh.cv.notify_all();
-      }
-      if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
       // kernel time of this launch; waits for the track kernel only -- its finalize and copies are already queued
       // behind it, so the next launch reaches the stream before they drain
       float ms = 0.f;
@@ -185,6 +179,12 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       kms[i] = ms;
       kernel_s += ms * 1e-3;
       t_last_kernel = now_s();
+      {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.queued = i + 1;
+        sh.cv.notify_all();
+      }
+      if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
     }
     writer.join();
     {

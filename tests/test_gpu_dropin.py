@@ -97,3 +97,22 @@ def test_mcsimulation_mirror_runs_air_and_object_scans(engine, tmp_path):
     assert 2.3 < mu_ref < 5.0, mu_ref  # ~20 cm of water incl. scatter build-up
     assert abs(mu_gpu - mu_ref) < 0.03 * mu_ref, (mu_gpu, mu_ref)
     assert abs(ab[lit].mean() / abr[lit].mean() - 1.0) < 0.01
+
+
+def test_executable_sharded_over_devices_equals_single_device(engine, tmp_path):
+    """`--gpus N` path of the drop-in executable (one host thread per device, integer sum of the tallies, the reference's
+    MPI_Reduce): run as two shards on device 0, it must reproduce the single-device files bit for bit -- ASCII and stacks."""
+    a = cases.build_case("catphan64_ct", tmp_path / "one", n_histories=400_000)
+    b = cases.build_case("catphan64_ct", tmp_path / "two", n_histories=400_000)
+    r1 = subprocess.run([str(engine.EXE_PATH), str(a), "--stacks", "--crop", "128"], capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([str(engine.EXE_PATH), str(b), "--devices", "0,0", "--stacks", "--crop", "128"], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stdout[-2000:] + r2.stdout[-2000:]
+    assert not re.search("(?i)error", r1.stdout + r2.stdout)
+    names = sorted(f.name for f in (tmp_path / "one").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
+    assert len(names) == 4
+    data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]  # footer: the speed line is optional
+    for n in names:
+        assert data(tmp_path / "one" / n) == data(tmp_path / "two" / n), n
+    for m in ("total", "unscattered", "scattered"):
+        s1, s2 = engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / "two" / f"projections_{m}.mha")
+        assert s1.shape == (4, 96, 128) and np.array_equal(s1, s2), m
