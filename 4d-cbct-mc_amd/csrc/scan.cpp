@@ -79,11 +79,14 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     const int first = opt->first_projection > 0 ? opt->first_projection : 0;
     const int count = (opt->num_projections > 0) ? opt->num_projections : (int)nproj_all - first;
     if (first + count > nproj_all || count <= 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection range outside the trajectory"};
-    const unsigned long long H = opt->histories_per_projection ? opt->histories_per_projection : (unsigned long long)hist_in;
+    unsigned long long H = opt->histories_per_projection ? opt->histories_per_projection : (unsigned long long)hist_in;
+    // An input value below 95000 is a time budget in seconds per projection, not a history count (MC-GPU_v1.3.cu:650-655,
+    // :689-809: the reference runs a speed test and converts).  Calibrate on the first projection with a throw-away launch.
+    const bool by_time = !opt->histories_per_projection && hist_in < 95000;
     int blocks = 1, hpt_eff = (int)hpt;
     unsigned long long total = H;
     if (mode == MCGPU_MODE_COMPAT) ABI_OK(mcgpu_launch_shape(H, (int)tpb, (int)hpt, &blocks, &hpt_eff, &total));
-    const unsigned long long units = mode == MCGPU_MODE_COMPAT ? (unsigned long long)blocks * (unsigned long long)tpb : total;
+    unsigned long long units = mode == MCGPU_MODE_COMPAT ? (unsigned long long)blocks * (unsigned long long)tpb : total;
     const int cx = (opt->crop_nx > 0 && opt->crop_nx < nx) ? opt->crop_nx : (int)nx;
     const size_t words = (size_t)4 * nx * nz, plane = (size_t)cx * nz;
     const double sx = opt->pixel_spacing_x > 0 ? opt->pixel_spacing_x : px_x, sy = opt->pixel_spacing_y > 0 ? opt->pixel_spacing_y : px_z;
@@ -102,6 +105,27 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     HIP_OK(hipStreamCreate(&stream));
     HIP_OK(hipMalloc(&image_dev, words * 8));
     HIP_OK(hipMemsetAsync(image_dev, 0, words * 8, stream));
+    if (by_time) {
+      const unsigned long long probe = 4000000ULL;
+      const unsigned long long probe_units = mode == MCGPU_MODE_COMPAT ? (probe + (unsigned long long)hpt - 1) / (unsigned long long)hpt : probe;
+      float ms = 0.f;
+      for (int rep = 0; rep < 2; ++rep) {  // the first launch pays one-off costs
+        ABI_OK(mcgpu_launch_projection(ctx, first, mode, (int)seed, 0, probe_units, (int)hpt, image_dev, stream));
+        ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
+      }
+      HIP_OK(hipMemsetAsync(image_dev, 0, words * 8, stream));
+      ABI_OK(mcgpu_dose_clear(ctx));
+      const double rate = (double)probe / (ms > 0.f ? ms * 1e-3 : 1e-3);
+      H = (unsigned long long)(rate * (double)hist_in);
+      if (H < 100000ULL) H = 100000ULL;
+      total = H;
+      if (mode == MCGPU_MODE_COMPAT) ABI_OK(mcgpu_launch_shape(H, (int)tpb, (int)hpt, &blocks, &hpt_eff, &total));
+      units = mode == MCGPU_MODE_COMPAT ? (unsigned long long)blocks * (unsigned long long)tpb : total;
+      if (opt->progress) {
+        printf("       Time-limited run: %lld s per projection at %.3e x-rays/s -> %llu histories per projection\n", hist_in, rate, total);
+        fflush(stdout);
+      }
+    }
     for (int b = 0; b < 2; ++b) {
       HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));
       // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte; the event orders the accesses

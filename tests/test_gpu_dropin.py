@@ -20,7 +20,7 @@ def _read_like_reference(path, nz, nx, dtype=np.float32):
 
 
 def test_executable_compat_matches_oracle_and_log_contract(engine, tmp_path):
-    inp = cases.build_case("catphan64_ct", tmp_path, n_histories=19200 * 3)
+    inp = cases.build_case("catphan64_ct", tmp_path, n_histories=19200 * 5)  # >= 95000: below that the value is a time budget
     exe = engine.EXE_PATH
     assert exe.exists()
     res = subprocess.run([str(exe), str(inp), "--mode", "compat"], capture_output=True, text=True, timeout=600)
@@ -116,3 +116,16 @@ def test_executable_sharded_over_devices_equals_single_device(engine, tmp_path):
     for m in ("total", "unscattered", "scattered"):
         s1, s2 = engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / "two" / f"projections_{m}.mha")
         assert s1.shape == (4, 96, 128) and np.array_equal(s1, s2), m
+
+
+def test_executable_time_limited_run(engine, tmp_path):
+    """An input "number of histories" below 95000 is a time budget in seconds per projection (MC-GPU_v1.3.cu:650-655)."""
+    inp = cases.build_case("water", tmp_path, n_histories=1)
+    res = subprocess.run([str(engine.EXE_PATH), str(inp)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and not re.search("(?i)error", res.stdout), res.stdout[-2000:]
+    m = re.search(r"Time-limited run: 1 s per projection at ([0-9.e+]+) x-rays/s -> (\d+) histories", res.stdout)
+    assert m, res.stdout[-2000:]
+    rate, n = float(m.group(1)), int(m.group(2))
+    assert 0.5 * rate < n < 1.5 * rate and n > 1_000_000
+    (name,) = [f for f in tmp_path.iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name)]
+    assert f"Simulated x rays:    {n}" in name.read_text()
