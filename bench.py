@@ -229,6 +229,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "track_pool_kernel<u8> (fast)", "kernel_ms_avg": k_ms,
                          "algorithmic_bytes_per_history": ALGO_BYTES_PER_HISTORY, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_HISTORY * H},
+            # second ceiling: one scattered 64-bit atomic add per detected photon; rate measured by
+            # tools/micro/atomic_rate.hip on MI355X = 2.37e10/s; detected photons per history of this workload = 0.754
+            "atomic_roofline": {"bound": "scattered 64-bit atomic adds", "achieved": 0.754 * H / (k_ms * 1e-3) / 1e9, "peak": 23.7,
+                                "unit": "Gatomic/s", "frac": 0.754 * H / (k_ms * 1e-3) / 23.7e9},
             "timing": {"prepare_inputs_s": t_prep, "load_and_upload_s": t_load},
             "check": {"detected_energy_units_last_projection": detected},
         }
