@@ -29,7 +29,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(unsigned long long* image
   }
 }
 
+// dst += src over the tally words (the integer sum of the reference's MPI_Reduce, MC-GPU_v1.3.cu:1019)
+__global__ __launch_bounds__(256) void accumulate_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
 }  // namespace
+
+hipError_t launch_accumulate(unsigned long long* dst, const unsigned long long* src, size_t words, hipStream_t stream) {
+  hipLaunchKernelGGL(accumulate_kernel, dim3(2048), dim3(256), 0, stream, dst, src, words);
+  return hipGetLastError();
+}
 
 hipError_t launch_finalize(unsigned long long* image, int nx, int nz, int crop_nx, double norm, float* planes, int clear, hipStream_t stream) {
   const dim3 block(256), grid((unsigned)((nx + 255) / 256), (unsigned)nz);

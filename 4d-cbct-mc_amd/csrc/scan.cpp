@@ -1,11 +1,17 @@
-// scan.cpp -- mcgpu_run_scan: the projection loop of main() (docker/mcgpu/MC-GPU_v1.3.cu:667-1056) as a device/host
-// pipeline, written on top of the engine's own C ABI.
+// scan.cpp -- mcgpu_run_scan / mcgpu_run_scan_multi: the projection loop of main() (docker/mcgpu/MC-GPU_v1.3.cu:667-1056)
+// as a device/host pipeline, written on top of the engine's own C ABI.
 //
-// Reference flow per projection, all on one host thread: kernel -> D2H of the 45 MB tally -> (MPI reduce) -> ~0.9 s of
-// fprintf -> re-zero.  Here, per projection and on one HIP stream: track kernel -> [u64 copy to pinned memory, only when
-// the ASCII files are wanted] -> finalize kernel (float32 planes + clears the tally) -> copy of the planes (9 MB) to
-// one of two pinned buffers -> event.  A writer thread waits on the event and appends the planes to the three MetaImage
-// stacks (and formats the ASCII file) while the GPU is already tracking the next projection.
+// Reference flow per projection, all on one host thread per rank: kernel -> D2H of the 45 MB tally -> MPI_Reduce to rank 0
+// (:1019) -> ~0.9 s of fprintf -> re-zero.  Here, per projection:
+//   every device g : [clear its tally buffer b] -> track kernel for its shard of the histories      (stream of device g)
+//   device 0       : wait for the peers' kernels -> peer copies of their tallies (xGMI) -> integer adds
+//                    -> [u64 copy to pinned memory, only when the ASCII files are wanted]
+//                    -> finalize kernel (float32 planes + clears the tally) -> copy of the planes (9 MB) to one of two
+//                    pinned buffers -> event                                                        (reduce stream)
+//   writer thread  : waits on the event, appends the planes to the three MetaImage stacks, formats the ASCII file.
+// Tally buffers are double-buffered on every device, so projection i + 1 is tracked while projection i is reduced,
+// finalized and written: the GPUs never wait for output or for each other's reduce.  History sharding keeps per-history
+// RNG streams and integer tallies, so the result is identical for any number of devices (tests run two "devices" on one).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -19,6 +25,10 @@
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
+
+namespace mcgpu {
+hipError_t launch_accumulate(unsigned long long* dst, const unsigned long long* src, size_t words, hipStream_t stream);  // finalize.hip
+}
 
 namespace {
 
@@ -39,17 +49,29 @@ struct ScanError {
     if (_rc != 0) throw ScanError{_rc, std::string(mcgpu_last_error())}; \
   } while (0)
 
+struct DeviceLane {  // per device
+  mcgpu_ctx* ctx = nullptr;
+  int dev = -1;
+  hipStream_t stream = nullptr;
+  void* image[2] = {nullptr, nullptr};
+  hipEvent_t tracked[2] = {nullptr, nullptr};  // track kernel into image[b] finished
+  hipEvent_t drained[2] = {nullptr, nullptr};  // image[b] has been consumed by device 0 (peer copy / finalize) and may be reused
+  void* staging = nullptr;                     // on device 0: landing buffer of this peer's tally
+  unsigned long long lo = 0, hi = 0;           // shard of the units of every projection
+};
+
 }  // namespace
 
 extern "C" void mcgpu_set_last_error_(const char* message);  // engine.cpp (not part of the public ABI)
 
-extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
-  if (!ctx || !opt) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
-  void *image_dev = nullptr, *planes_dev[2] = {nullptr, nullptr};
+extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
+  if (!ctxs || n_ctx < 1 || !opt || !ctxs[0]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
+  std::vector<DeviceLane> D((size_t)n_ctx);
+  void* planes_dev[2] = {nullptr, nullptr};
   float* planes_host[2] = {nullptr, nullptr};
   uint64_t* image_host[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
-  hipStream_t stream = nullptr;
+  hipStream_t reduce_stream = nullptr;
   mcgpu_stack* stacks[3] = {nullptr, nullptr, nullptr};
   std::thread writer;
   struct Shared {
@@ -60,9 +82,10 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     std::string error;
     double writer_s = 0.0;
   } sh;
+  mcgpu_ctx* ctx = ctxs[0];
   int rc = 0;
   try {
-    long long nproj_all = 1, hist_in = 0, seed = 0, tpb = 128, hpt = 150, nx = 0, nz = 0, dev = 0;
+    long long nproj_all = 1, hist_in = 0, seed = 0, tpb = 128, hpt = 150, nx = 0, nz = 0;
     ABI_OK(mcgpu_config_i64(ctx, "num_projections", &nproj_all));
     ABI_OK(mcgpu_config_i64(ctx, "total_histories", &hist_in));
     ABI_OK(mcgpu_config_i64(ctx, "seed", &seed));
@@ -70,8 +93,14 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     ABI_OK(mcgpu_config_i64(ctx, "histories_per_thread", &hpt));
     ABI_OK(mcgpu_config_i64(ctx, "num_pixels_x", &nx));
     ABI_OK(mcgpu_config_i64(ctx, "num_pixels_z", &nz));
-    ABI_OK(mcgpu_config_i64(ctx, "device_id", &dev));
-    if (dev < 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: the context has no device"};
+    for (int g = 0; g < n_ctx; ++g) {
+      long long dev = -1;
+      if (!ctxs[g]) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: null context"};
+      ABI_OK(mcgpu_config_i64(ctxs[g], "device_id", &dev));
+      if (dev < 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: a context has no device"};
+      D[g].ctx = ctxs[g];
+      D[g].dev = (int)dev;
+    }
     double px_x = 0, px_z = 0;
     ABI_OK(mcgpu_config_f64(ctx, "pixel_size_x_mm", &px_x));
     ABI_OK(mcgpu_config_f64(ctx, "pixel_size_z_mm", &px_z));
@@ -81,7 +110,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
     if (first + count > nproj_all || count <= 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection range outside the trajectory"};
     unsigned long long H = opt->histories_per_projection ? opt->histories_per_projection : (unsigned long long)hist_in;
     // An input value below 95000 is a time budget in seconds per projection, not a history count (MC-GPU_v1.3.cu:650-655,
-    // :689-809: the reference runs a speed test and converts).  Calibrate on the first projection with a throw-away launch.
+    // :689-809: the reference runs a speed test and converts).  Calibrate on device 0 with a throw-away launch.
     const bool by_time = !opt->histories_per_projection && hist_in < 95000;
     int blocks = 1, hpt_eff = (int)hpt;
     unsigned long long total = H;
@@ -100,22 +129,38 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       folder = slash == std::string::npos ? "." : folder.substr(0, slash);
     }
 
-    HIP_OK(hipSetDevice((int)dev));
+    // ---- device resources
     const unsigned int pinned_flags = getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent;
-    HIP_OK(hipStreamCreate(&stream));
-    HIP_OK(hipMalloc(&image_dev, words * 8));
-    HIP_OK(hipMemsetAsync(image_dev, 0, words * 8, stream));
+    for (int g = 0; g < n_ctx; ++g) {
+      HIP_OK(hipSetDevice(D[g].dev));
+      HIP_OK(hipStreamCreate(&D[g].stream));
+      for (int b = 0; b < 2; ++b) {
+        HIP_OK(hipMalloc(&D[g].image[b], words * 8));
+        HIP_OK(hipMemsetAsync(D[g].image[b], 0, words * 8, D[g].stream));
+        HIP_OK(hipEventCreateWithFlags(&D[g].tracked[b], hipEventDisableTiming));
+      }
+    }
+    HIP_OK(hipSetDevice(D[0].dev));
+    // One device: tracking, finalize and copies share one stream and one tally buffer (finalize takes 20 us between two
+    // 9 ms kernels; a second buffer only adds 45 MB to the footprint the atomics have to keep in the Infinity Cache).
+    // Several devices: the reduce runs on its own stream of device 0, beside the next projection's tracking.
+    const bool single = (n_ctx == 1);
+    if (single) reduce_stream = D[0].stream;
+    else HIP_OK(hipStreamCreate(&reduce_stream));
+    for (int g = 0; g < n_ctx; ++g)  // recorded on device 0's reduce stream, so they belong to device 0
+      for (int b = 0; b < 2; ++b) HIP_OK(hipEventCreateWithFlags(&D[g].drained[b], hipEventDisableTiming));
+    for (int g = 1; g < n_ctx; ++g) HIP_OK(hipMalloc(&D[g].staging, words * 8));
     if (by_time) {
       const unsigned long long probe = 4000000ULL;
       const unsigned long long probe_units = mode == MCGPU_MODE_COMPAT ? (probe + (unsigned long long)hpt - 1) / (unsigned long long)hpt : probe;
       float ms = 0.f;
       for (int rep = 0; rep < 2; ++rep) {  // the first launch pays one-off costs
-        ABI_OK(mcgpu_launch_projection(ctx, first, mode, (int)seed, 0, probe_units, (int)hpt, image_dev, stream));
+        ABI_OK(mcgpu_launch_projection(ctx, first, mode, (int)seed, 0, probe_units, (int)hpt, D[0].image[0], D[0].stream));
         ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
       }
-      HIP_OK(hipMemsetAsync(image_dev, 0, words * 8, stream));
+      HIP_OK(hipMemsetAsync(D[0].image[0], 0, words * 8, D[0].stream));
       ABI_OK(mcgpu_dose_clear(ctx));
-      const double rate = (double)probe / (ms > 0.f ? ms * 1e-3 : 1e-3);
+      const double rate = (double)probe / (ms > 0.f ? ms * 1e-3 : 1e-3) * n_ctx;
       H = (unsigned long long)(rate * (double)hist_in);
       if (H < 100000ULL) H = 100000ULL;
       total = H;
@@ -126,6 +171,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
         fflush(stdout);
       }
     }
+    for (int g = 0; g < n_ctx; ++g) { D[g].lo = units * g / n_ctx; D[g].hi = units * (g + 1) / n_ctx; }
     for (int b = 0; b < 2; ++b) {
       HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));
       // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte; the event orders the accesses
@@ -150,7 +196,7 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
           if (sh.abort) return;
         }
         const int b = i & 1, p = first + i;
-        if (hipSetDevice((int)dev) != hipSuccess || hipEventSynchronize(done[b]) != hipSuccess) {
+        if (hipSetDevice(D[0].dev) != hipSuccess || hipEventSynchronize(done[b]) != hipSuccess) {
           std::lock_guard<std::mutex> lk(sh.mu);
           sh.error = "!!HIP ERROR!! waiting for projection results";
           sh.abort = true;
@@ -182,7 +228,8 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
       for (int p = 0; p < first; ++p) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
     for (int i = 0; i < count; ++i) {
       const int b = i & 1, p = first + i;
-      {  // buffer b is free once projection i-2 has been written
+      const int t = single ? 0 : b;  // tally buffer of this projection
+      {  // pinned buffer b is free once projection i-2 has been written
         std::unique_lock<std::mutex> lk(sh.mu);
         sh.cv.wait(lk, [&] { return sh.written >= i - 1 || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
@@ -191,15 +238,36 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
         printf("\n\n\n   << Simulating Projection %d of %d >>\n\n\n", p + 1, (int)nproj_all);  // cbctmc/mc/simulation.py:200-219 parses this
         fflush(stdout);
       }
-      ABI_OK(mcgpu_launch_projection(ctx, p, mode, cur_seed, 0, units, hpt_eff, image_dev, stream));
-      if (opt->write_ascii) HIP_OK(hipMemcpyAsync(image_host[b], image_dev, words * 8, hipMemcpyDeviceToHost, stream));
-      ABI_OK(mcgpu_finalize_projection(ctx, image_dev, total, cx, planes_dev[b], 1, stream));
-      HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, stream));
-      HIP_OK(hipEventRecord(done[b], stream));
-      // kernel time of this launch; waits for the track kernel only -- its finalize and copies are already queued
-      // behind it, so the next launch reaches the stream before they drain
+      // every device tracks its shard into its tally buffer b (already zero: finalize / the memset below cleared it)
+      for (int g = 0; g < n_ctx; ++g) {
+        HIP_OK(hipSetDevice(D[g].dev));
+        if (!single && i >= 2) HIP_OK(hipStreamWaitEvent(D[g].stream, D[g].drained[t], 0));  // projection i-2's tally has been consumed
+        if (g > 0 && i >= 2) HIP_OK(hipMemsetAsync(D[g].image[t], 0, words * 8, D[g].stream));
+        ABI_OK(mcgpu_launch_projection(D[g].ctx, p, mode, cur_seed, D[g].lo, D[g].hi - D[g].lo, hpt_eff, D[g].image[t], D[g].stream));
+        HIP_OK(hipEventRecord(D[g].tracked[t], D[g].stream));
+      }
+      // device 0: gather, add, finalize
+      HIP_OK(hipSetDevice(D[0].dev));
+      if (!single) HIP_OK(hipStreamWaitEvent(reduce_stream, D[0].tracked[t], 0));
+      for (int g = 1; g < n_ctx; ++g) {
+        HIP_OK(hipStreamWaitEvent(reduce_stream, D[g].tracked[t], 0));
+        HIP_OK(hipMemcpyPeerAsync(D[g].staging, D[0].dev, D[g].image[t], D[g].dev, words * 8, reduce_stream));
+        HIP_OK(hipEventRecord(D[g].drained[t], reduce_stream));
+        HIP_OK(mcgpu::launch_accumulate((unsigned long long*)D[0].image[t], (const unsigned long long*)D[g].staging, words, reduce_stream));
+      }
+      if (opt->write_ascii) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, reduce_stream));
+      ABI_OK(mcgpu_finalize_projection(ctx, D[0].image[t], total, cx, planes_dev[b], 1, reduce_stream));
+      HIP_OK(hipEventRecord(D[0].drained[t], reduce_stream));
+      HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, reduce_stream));
+      HIP_OK(hipEventRecord(done[b], reduce_stream));
+      // kernel time of this projection = the slowest device's launch; waiting for it also paces the host: at most two
+      // projections are in flight
       float ms = 0.f;
-      ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
+      for (int g = 0; g < n_ctx; ++g) {
+        float m = 0.f;
+        ABI_OK(mcgpu_last_kernel_ms(D[g].ctx, &m));
+        ms = m > ms ? m : ms;
+      }
       kms[i] = ms;
       kernel_s += ms * 1e-3;
       t_last_kernel = now_s();
@@ -247,14 +315,39 @@ extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcg
   }
   for (int k = 0; k < 3; ++k)
     if (stacks[k]) (void)mcgpu_stack_finish(stacks[k], 0, nullptr);  // error path: close the files
-  if (stream) (void)hipStreamSynchronize(stream);
-  for (int b = 0; b < 2; ++b) {
-    if (planes_dev[b]) (void)hipFree(planes_dev[b]);
-    if (planes_host[b]) (void)hipHostFree(planes_host[b]);
-    if (image_host[b]) (void)hipHostFree(image_host[b]);
-    if (done[b]) (void)hipEventDestroy(done[b]);
+  for (auto& d : D) {
+    if (d.dev < 0) continue;
+    (void)hipSetDevice(d.dev);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
   }
-  if (image_dev) (void)hipFree(image_dev);
-  if (stream) (void)hipStreamDestroy(stream);
+  if (D[0].dev >= 0) {
+    (void)hipSetDevice(D[0].dev);
+    if (reduce_stream && n_ctx > 1) (void)hipStreamSynchronize(reduce_stream);
+    for (int b = 0; b < 2; ++b) {
+      if (planes_dev[b]) (void)hipFree(planes_dev[b]);
+      if (planes_host[b]) (void)hipHostFree(planes_host[b]);
+      if (image_host[b]) (void)hipHostFree(image_host[b]);
+      if (done[b]) (void)hipEventDestroy(done[b]);
+    }
+    for (auto& d : D) {
+      if (d.staging) (void)hipFree(d.staging);
+      for (int b = 0; b < 2; ++b)
+        if (d.drained[b]) (void)hipEventDestroy(d.drained[b]);
+    }
+    if (reduce_stream && n_ctx > 1) (void)hipStreamDestroy(reduce_stream);
+  }
+  for (auto& d : D) {
+    if (d.dev < 0) continue;
+    (void)hipSetDevice(d.dev);
+    for (int b = 0; b < 2; ++b) {
+      if (d.image[b]) (void)hipFree(d.image[b]);
+      if (d.tracked[b]) (void)hipEventDestroy(d.tracked[b]);
+    }
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+  }
   return rc;
+}
+
+extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
+  return mcgpu_run_scan_multi(&ctx, 1, opt, report);
 }

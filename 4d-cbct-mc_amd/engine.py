@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
-    "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
+    "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume",
     "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math",
 )
@@ -106,6 +106,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_stack_read.argtypes = [cp, C.POINTER(ci), vp, C.c_size_t]
     lib.mcgpu_normalize_stack.argtypes = [cp, cp, C.c_double, C.c_double, cp, C.c_double, C.c_double]
     lib.mcgpu_run_scan.argtypes = [vp, C.POINTER(ScanOptions), C.POINTER(ScanReport)]
+    lib.mcgpu_run_scan_multi.argtypes = [C.POINTER(vp), ci, C.POINTER(ScanOptions), C.POINTER(ScanReport)]
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
     lib.mcgpu_write_voxel_binary.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
@@ -364,7 +365,7 @@ class Context:
 
     def run_scan(self, mode="fast", first_projection=0, num_projections=0, histories=0, crop_nx=0, write_ascii=False, write_stacks=True,
                  output_folder=None, air_stack=None, air_sigma=(10.0, 10.0), pixel_spacing=(0.0, 0.0), shared_stacks=None,
-                 slice_of_projection=None) -> dict:
+                 slice_of_projection=None, peers=()) -> dict:
         """The whole projection loop as a device/host pipeline (mcgpu_run_scan); returns the timing report.
         `shared_stacks` = three open StackWriters (total, unscattered, scattered) filled by slice index (4-D scans)."""
         o = ScanOptions()
@@ -379,7 +380,11 @@ class Context:
         o.air_sigma_y, o.air_sigma_x = (float(air_sigma[0]), float(air_sigma[1])) if air_sigma else (0.0, 0.0)
         o.pixel_spacing_x, o.pixel_spacing_y = float(pixel_spacing[0]), float(pixel_spacing[1])
         r = ScanReport()
-        _check(self.lib.mcgpu_run_scan(self.h, C.byref(o), C.byref(r)))
+        if peers:  # contexts of the same input on other devices: histories sharded, tallies reduced on this context's device
+            hs = (C.c_void_p * (1 + len(peers)))(self.h, *[p.h for p in peers])
+            _check(self.lib.mcgpu_run_scan_multi(hs, 1 + len(peers), C.byref(o), C.byref(r)))
+        else:
+            _check(self.lib.mcgpu_run_scan(self.h, C.byref(o), C.byref(r)))
         return {"projections": r.projections, "histories_per_projection": r.histories_per_projection, "seconds_total": r.seconds_total,
                 "seconds_kernels": r.seconds_kernels, "seconds_after_last_kernel": r.seconds_after_last_kernel,
                 "seconds_writer": r.seconds_writer, "zero_replacement": [float(v) for v in r.zero_replacement]}

@@ -172,6 +172,12 @@ typedef struct mcgpu_scan_report {
   double seconds_writer;                        /* busy time of the output thread (overlapped with tracking) */
 } mcgpu_scan_report;
 int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
+/* The same over several devices of one node (contexts created from the same input file, one per device): every
+ * projection's histories are sharded over the contexts (the reference's `mpirun -n N`, MC-GPU_v1.3.cu:728-731,823-841), the
+ * per-device tallies are copied to the first context's device peer-to-peer and added there (the MPI_Reduce of :1019), then
+ * finalized and written as above.  Tally buffers are double-buffered per device: no device waits for the reduce.  Dose
+ * tallies stay per context (sum them with mcgpu_dose_read). */
+int mcgpu_run_scan_multi(mcgpu_ctx *const *ctxs, int n_ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
 
 /* ---- 4-D: one resident context for many (geometry, projection angles) jobs (cbctmc/mc/simulation.py:527-710 launches the
  * engine once per respiratory state) ----

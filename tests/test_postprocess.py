@@ -180,3 +180,37 @@ def test_device_finalize_and_scan_pipeline(engine, case_dir, tmp_path):
             ctx.write_projection(p, per_proj[p], n_hist, file_name=str(ref_file))
             data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]  # footer: the speed line is optional
             assert data(name) == data(ref_file)
+
+
+@pytest.mark.gpu
+def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_path):
+    """mcgpu_run_scan_multi: three contexts (here on one device) shard the histories, the first one's device reduces the
+    tallies peer to peer, finalizes and writes; stacks and ASCII files equal the single-context scan bit for bit."""
+    n_hist = 500_000
+    outs = []
+    for k, n_peers in enumerate((0, 2)):
+        out = tmp_path / f"scan{k}"
+        out.mkdir()
+        ctxs = [engine.create(case_dir("catphan64_ct"), device=0) for _ in range(1 + n_peers)]
+        try:
+            rep = ctxs[0].run_scan(mode="fast", histories=n_hist, crop_nx=128, write_ascii=False, output_folder=out, peers=ctxs[1:])
+            assert rep["projections"] == 4 and rep["histories_per_projection"] == n_hist
+        finally:
+            for c in ctxs:
+                c.close()
+        outs.append({m: engine.stack_read(out / f"projections_{m}.mha") for m in ("total", "unscattered", "scattered")})
+    for m in outs[0]:
+        assert np.array_equal(outs[0][m], outs[1][m]), m
+    # COMPAT mode shards RANECU batches: same statement
+    res = []
+    for n_peers in (0, 1):
+        out = tmp_path / f"compat{n_peers}"
+        out.mkdir()
+        ctxs = [engine.create(case_dir("catphan64_ct"), device=0) for _ in range(1 + n_peers)]
+        try:
+            ctxs[0].run_scan(mode="compat", histories=19200 * 5, crop_nx=0, output_folder=out, peers=ctxs[1:])
+        finally:
+            for c in ctxs:
+                c.close()
+        res.append(engine.stack_read(out / "projections_total.mha"))
+    assert np.array_equal(res[0], res[1])
