@@ -32,6 +32,7 @@ constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kSlotWords = 13;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kNumStats = 16;             // scheduler counters of the diagnostic build
+constexpr int kWaveTrace = 16384;         // diagnostic build: {hardware id, first and last clock} of up to this many waves follow the counters
 constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
 
 // Byte offsets of the kernel's dynamic LDS image (track_common.inc: stage_tables).  Sized for the materials and

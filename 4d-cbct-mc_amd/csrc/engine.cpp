@@ -650,7 +650,11 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         if (D.resident_fast <= 0) D.resident_fast = 1;
       }
       const unsigned long long want = (count + kPoolBlockThreads - 1) / kPoolBlockThreads;
-      const unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
+      unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
+      {  // spare workgroups (percent of the resident grid): see the kernel's prologue
+        const char* v = getenv("MCGPU_GRID_SPARE_PERCENT");
+        resident += resident * (unsigned long long)(v ? std::max(0, atoi(v)) : 0) / 100ULL;
+      }
       {  // FAST scheduling knobs live in TrackCold; the environment may change them between launches (tuning sweeps)
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         TrackCold& ch = D.cold_host;
@@ -667,7 +671,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       HIP_TRY(hipMemsetAsync(D.work_counter, 0, 8, stream));
       A.work_counter = D.work_counter;
       if (mode == MCGPU_MODE_FAST_STATS) {
-        if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats, 0ULL));
+        if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats + 3 * kWaveTrace, 0ULL));
         A.stats = D.stats;
         HIP_TRY(launch_track_stats(A, (int)std::min(want, resident), stream));
       } else {
@@ -685,12 +689,12 @@ int mcgpu_scheduler_stats_ex(mcgpu_ctx* ctx, unsigned long long* out, int capaci
   ABI_BEGIN
   require(ctx && ctx->has_device && out && capacity > 0, -1, "!!ERROR!! mcgpu_scheduler_stats: bad argument");
   HIP_TRY(hipSetDevice(ctx->dev.device_id));
-  const int n = std::min(capacity, kNumStats);
+  const int n = std::min(capacity, kNumStats + 3 * kWaveTrace);  // counters, then the wave trace (device_model.hpp)
   for (int k = 0; k < capacity; ++k) out[k] = 0;
   if (!ctx->dev.stats) return 0;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, ctx->dev.stats, (size_t)n * 8, hipMemcpyDeviceToHost));
-  if (reset) HIP_TRY(hipMemset(ctx->dev.stats, 0, (size_t)kNumStats * 8));
+  if (reset) HIP_TRY(hipMemset(ctx->dev.stats, 0, (size_t)(kNumStats + 3 * kWaveTrace) * 8));
   return 0;
   ABI_END
 }

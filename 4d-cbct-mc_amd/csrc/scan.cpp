@@ -2,16 +2,21 @@
 // as a device/host pipeline, written on top of the engine's own C ABI.
 //
 // Reference flow per projection, all on one host thread per rank: kernel -> D2H of the 45 MB tally -> MPI_Reduce to rank 0
-// (:1019) -> ~0.9 s of fprintf -> re-zero.  Here, per projection:
-//   every device g : [clear its tally buffer b] -> track kernel for its shard of the histories      (stream of device g)
-//   device 0       : wait for the peers' kernels -> peer copies of their tallies (xGMI) -> integer adds
-//                    -> [u64 copy to pinned memory, only when the ASCII files are wanted]
-//                    -> finalize kernel (float32 planes + clears the tally) -> copy of the planes (9 MB) to one of two
-//                    pinned buffers -> event                                                        (reduce stream)
-//   writer thread  : waits on the event, appends the planes to the three MetaImage stacks, formats the ASCII file.
-// Tally buffers are double-buffered on every device, so projection i + 1 is tracked while projection i is reduced,
-// finalized and written: the GPUs never wait for output or for each other's reduce.  History sharding keeps per-history
-// RNG streams and integer tallies, so the result is identical for any number of devices (tests run two "devices" on one).
+// (:1019) -> ~0.9 s of fprintf -> re-zero.  Here every device has ONE stream and everything a device does is ordered on it:
+//   peer g > 0 : track kernel for its shard of projection i -> push of its tally into a landing buffer on device 0
+//                (xGMI, one of two per peer) -> clear the tally
+//   device 0   : track kernel for its shard of projection i (tally buffer i & 1)
+//                -> REDUCE of projection i - 1: integer adds of the landed peer tallies -> [u64 copy to pinned memory, only
+//                when the ASCII files are wanted] -> finalize kernel (float32 planes + clears the tally) -> copy of the
+//                planes (9 MB) to one of two pinned buffers -> event
+//   writer thread : waits on the event, appends the planes to the three MetaImage stacks, formats the ASCII file.
+// The one-projection lag means device 0 never waits for a push (it had a whole kernel's time to land), and nothing ever
+// runs BESIDE a tracking launch: a kernel that is still resident while the persistent tracking grid is dispatched
+// fragments the CUs' register files for that whole launch (144 of 256 CUs then hold one workgroup instead of two:
+// 9.2 -> 12.5 ms, tools/placement_probe.py), so a separate "reduce stream" is slower than no overlap.
+// With one device the lag is zero and there is a single tally buffer (finalize takes 20 us between two 9 ms kernels).
+// History sharding keeps per-history RNG streams and integer tallies, so the result is identical for any number of
+// devices (tests run two "devices" on one).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -53,10 +58,9 @@ struct DeviceLane {  // per device
   mcgpu_ctx* ctx = nullptr;
   int dev = -1;
   hipStream_t stream = nullptr;
-  void* image[2] = {nullptr, nullptr};
-  hipEvent_t tracked[2] = {nullptr, nullptr};  // track kernel into image[b] finished
-  hipEvent_t drained[2] = {nullptr, nullptr};  // image[b] has been consumed by device 0 (peer copy / finalize) and may be reused
-  void* staging = nullptr;                     // on device 0: landing buffer of this peer's tally
+  void* image[2] = {nullptr, nullptr};         // tally buffers (device 0 of a multi-device scan uses both, everyone else [0])
+  void* landing[2] = {nullptr, nullptr};       // peers: on device 0, where this peer's tally of projection i lands (i & 1)
+  hipEvent_t pushed[2] = {nullptr, nullptr};   // peers: the push into landing[b] has finished (recorded on the peer's stream)
   unsigned long long lo = 0, hi = 0;           // shard of the units of every projection
 };
 
@@ -71,7 +75,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   float* planes_host[2] = {nullptr, nullptr};
   uint64_t* image_host[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
-  hipStream_t reduce_stream = nullptr;
+  hipEvent_t consumed[2] = {nullptr, nullptr};  // device 0 has added the landing buffers b of all peers
   mcgpu_stack* stacks[3] = {nullptr, nullptr, nullptr};
   std::thread writer;
   struct Shared {
@@ -106,8 +110,20 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     ABI_OK(mcgpu_config_f64(ctx, "pixel_size_z_mm", &px_z));
     const int mode = opt->mode == MCGPU_MODE_COMPAT ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
     const int first = opt->first_projection > 0 ? opt->first_projection : 0;
-    const int count = (opt->num_projections > 0) ? opt->num_projections : (int)nproj_all - first;
-    if (first + count > nproj_all || count <= 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection range outside the trajectory"};
+    const int range = (opt->num_projections > 0) ? opt->num_projections : (int)nproj_all - first;
+    if (first + range > nproj_all || range <= 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection range outside the trajectory"};
+    // projections outside the input's angular region of interest are not simulated (MC-GPU_v1.3.cu:670-677; like the
+    // reference, the test uses initial_angle + p * D_angle even when specific angles are given)
+    double d_angle = -1.0, angle0 = 0.0, roi0 = 0.0, roi1 = 0.0;
+    ABI_OK(mcgpu_config_f64(ctx, "D_angle", &d_angle));
+    ABI_OK(mcgpu_config_f64(ctx, "initial_angle", &angle0));
+    ABI_OK(mcgpu_config_f64(ctx, "angularROI_0", &roi0));
+    ABI_OK(mcgpu_config_f64(ctx, "angularROI_1", &roi1));
+    auto outside_roi = [&](int p) { const double a = angle0 + p * d_angle; return a < roi0 || a > roi1; };
+    std::vector<int> sim;  // offsets within the range of the projections that are simulated
+    for (int k = 0; k < range; ++k)
+      if (!outside_roi(first + k)) sim.push_back(k);
+    const int count = (int)sim.size();
     unsigned long long H = opt->histories_per_projection ? opt->histories_per_projection : (unsigned long long)hist_in;
     // An input value below 95000 is a time budget in seconds per projection, not a history count (MC-GPU_v1.3.cu:650-655,
     // :689-809: the reference runs a speed test and converts).  Calibrate on device 0 with a throw-away launch.
@@ -131,25 +147,23 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
 
     // ---- device resources
     const unsigned int pinned_flags = getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent;
+    const bool single = (n_ctx == 1);
     for (int g = 0; g < n_ctx; ++g) {
       HIP_OK(hipSetDevice(D[g].dev));
       HIP_OK(hipStreamCreate(&D[g].stream));
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < ((g == 0 && !single) ? 2 : 1); ++b) {
         HIP_OK(hipMalloc(&D[g].image[b], words * 8));
         HIP_OK(hipMemsetAsync(D[g].image[b], 0, words * 8, D[g].stream));
-        HIP_OK(hipEventCreateWithFlags(&D[g].tracked[b], hipEventDisableTiming));
       }
+      if (g > 0)
+        for (int b = 0; b < 2; ++b) HIP_OK(hipEventCreateWithFlags(&D[g].pushed[b], hipEventDisableTiming));
     }
     HIP_OK(hipSetDevice(D[0].dev));
-    // One device: tracking, finalize and copies share one stream and one tally buffer (finalize takes 20 us between two
-    // 9 ms kernels; a second buffer only adds 45 MB to the footprint the atomics have to keep in the Infinity Cache).
-    // Several devices: the reduce runs on its own stream of device 0, beside the next projection's tracking.
-    const bool single = (n_ctx == 1);
-    if (single) reduce_stream = D[0].stream;
-    else HIP_OK(hipStreamCreate(&reduce_stream));
-    for (int g = 0; g < n_ctx; ++g)  // recorded on device 0's reduce stream, so they belong to device 0
-      for (int b = 0; b < 2; ++b) HIP_OK(hipEventCreateWithFlags(&D[g].drained[b], hipEventDisableTiming));
-    for (int g = 1; g < n_ctx; ++g) HIP_OK(hipMalloc(&D[g].staging, words * 8));
+    hipStream_t const s0 = D[0].stream;
+    for (int b = 0; b < 2 && !single; ++b) {
+      HIP_OK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+      for (int g = 1; g < n_ctx; ++g) HIP_OK(hipMalloc(&D[g].landing[b], words * 8));
+    }
     if (by_time) {
       const unsigned long long probe = 4000000ULL;
       const unsigned long long probe_units = mode == MCGPU_MODE_COMPAT ? (probe + (unsigned long long)hpt - 1) / (unsigned long long)hpt : probe;
@@ -181,7 +195,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     }
     const bool shared = opt->shared_stacks != nullptr;  // 4-D: the caller owns stacks that several scans fill by slice index
     if (shared && !opt->slice_of_projection) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: shared_stacks needs slice_of_projection"};
-    if (opt->write_stacks && !shared) {
+    if (opt->write_stacks && !shared && count > 0) {
       static const char* kNames[3] = {"projections_total.mha", "projections_unscattered.mha", "projections_scattered.mha"};
       for (int k = 0; k < 3; ++k) ABI_OK(mcgpu_stack_create((folder + "/" + kNames[k]).c_str(), cx, (int)nz, count, sx, sy, &stacks[k]));
     }
@@ -195,7 +209,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
           sh.cv.wait(lk, [&] { return sh.queued > i || sh.abort; });
           if (sh.abort) return;
         }
-        const int b = i & 1, p = first + i;
+        const int b = i & 1, p = first + sim[i];
         if (hipSetDevice(D[0].dev) != hipSuccess || hipEventSynchronize(done[b]) != hipSuccess) {
           std::lock_guard<std::mutex> lk(sh.mu);
           sh.error = "!!HIP ERROR!! waiting for projection results";
@@ -207,7 +221,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         int wrc = 0;
         if (shared)
           for (int k = 0; k < 3 && wrc == 0; ++k)
-            wrc = mcgpu_stack_write_slice(opt->shared_stacks[k], opt->slice_of_projection[i], planes_host[b] + (size_t)k * plane);
+            wrc = mcgpu_stack_write_slice(opt->shared_stacks[k], opt->slice_of_projection[sim[i]], planes_host[b] + (size_t)k * plane);
         else if (opt->write_stacks)
           for (int k = 0; k < 3 && wrc == 0; ++k) wrc = mcgpu_stack_append(stacks[k], planes_host[b] + (size_t)k * plane);
         if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, (double)kms[i] * 1e-3, nullptr);
@@ -224,44 +238,62 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     const double t0 = now_s();
     double kernel_s = 0.0, t_last_kernel = t0;
     int cur_seed = (int)seed;
-    if (mode == MCGPU_MODE_COMPAT)
-      for (int p = 0; p < first; ++p) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
-    for (int i = 0; i < count; ++i) {
-      const int b = i & 1, p = first + i;
-      const int t = single ? 0 : b;  // tally buffer of this projection
-      {  // pinned buffer b is free once projection i-2 has been written
+    if (mode == MCGPU_MODE_COMPAT)  // the seed moves on per SIMULATED projection (MC-GPU_v1.3.cu:869)
+      for (int p = 0; p < first; ++p)
+        if (!outside_roi(p)) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
+    // reduce + finalize of projection j on device 0's stream, then hand it to the writer
+    auto enqueue_reduce = [&](int j) {
+      const int b = j & 1, t = single ? 0 : b;
+      {  // pinned buffer b is free once projection j-2 has been written
         std::unique_lock<std::mutex> lk(sh.mu);
-        sh.cv.wait(lk, [&] { return sh.written >= i - 1 || sh.abort; });
+        sh.cv.wait(lk, [&] { return sh.written >= j - 1 || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
+      HIP_OK(hipSetDevice(D[0].dev));
+      for (int g = 1; g < n_ctx; ++g) {
+        HIP_OK(hipStreamWaitEvent(s0, D[g].pushed[b], 0));
+        HIP_OK(mcgpu::launch_accumulate((unsigned long long*)D[0].image[t], (const unsigned long long*)D[g].landing[b], words, s0));
+      }
+      if (!single) HIP_OK(hipEventRecord(consumed[b], s0));
+      if (opt->write_ascii) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, s0));
+      ABI_OK(mcgpu_finalize_projection(ctx, D[0].image[t], total, cx, planes_dev[b], 1, s0));
+      HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, s0));
+      HIP_OK(hipEventRecord(done[b], s0));
+    };
+    auto publish = [&](int j) {  // kms[j] is final: the writer may take projection j
+      std::lock_guard<std::mutex> lk(sh.mu);
+      sh.queued = j + 1;
+      sh.cv.notify_all();
+    };
+    const double kRad2Deg = 180.0 / 3.14159265358979323846;
+    auto print_skipped = [&](int from, int to) {  // offsets [from, to) of the range
+      for (int k = from; k < to && opt->progress; ++k)
+        printf("         << Skipping projection #%d of %d >> Angle %f degrees: outside angular region of interest.\n", first + k + 1, (int)nproj_all,
+               (angle0 + (first + k) * d_angle) * kRad2Deg);
+    };
+    for (int i = 0; i < count; ++i) {
+      const int b = i & 1, p = first + sim[i];
+      print_skipped(i ? sim[i - 1] + 1 : 0, sim[i]);
       if (nproj_all != 1 && opt->progress) {
         printf("\n\n\n   << Simulating Projection %d of %d >>\n\n\n", p + 1, (int)nproj_all);  // cbctmc/mc/simulation.py:200-219 parses this
         fflush(stdout);
       }
-      // every device tracks its shard into its tally buffer b (already zero: finalize / the memset below cleared it)
+      // every device tracks its shard into a zeroed tally buffer; peers then push theirs to device 0 and clear it
       for (int g = 0; g < n_ctx; ++g) {
         HIP_OK(hipSetDevice(D[g].dev));
-        if (!single && i >= 2) HIP_OK(hipStreamWaitEvent(D[g].stream, D[g].drained[t], 0));  // projection i-2's tally has been consumed
-        if (g > 0 && i >= 2) HIP_OK(hipMemsetAsync(D[g].image[t], 0, words * 8, D[g].stream));
-        ABI_OK(mcgpu_launch_projection(D[g].ctx, p, mode, cur_seed, D[g].lo, D[g].hi - D[g].lo, hpt_eff, D[g].image[t], D[g].stream));
-        HIP_OK(hipEventRecord(D[g].tracked[t], D[g].stream));
+        void* const tally = D[g].image[(g == 0 && !single) ? b : 0];
+        ABI_OK(mcgpu_launch_projection(D[g].ctx, p, mode, cur_seed, D[g].lo, D[g].hi - D[g].lo, hpt_eff, tally, D[g].stream));
+        if (g > 0) {
+          if (i >= 2) HIP_OK(hipStreamWaitEvent(D[g].stream, consumed[b], 0));  // landing[b] still holds projection i-2 until then
+          HIP_OK(hipMemcpyPeerAsync(D[g].landing[b], D[0].dev, tally, D[g].dev, words * 8, D[g].stream));
+          HIP_OK(hipEventRecord(D[g].pushed[b], D[g].stream));
+          HIP_OK(hipMemsetAsync(tally, 0, words * 8, D[g].stream));
+        }
       }
-      // device 0: gather, add, finalize
-      HIP_OK(hipSetDevice(D[0].dev));
-      if (!single) HIP_OK(hipStreamWaitEvent(reduce_stream, D[0].tracked[t], 0));
-      for (int g = 1; g < n_ctx; ++g) {
-        HIP_OK(hipStreamWaitEvent(reduce_stream, D[g].tracked[t], 0));
-        HIP_OK(hipMemcpyPeerAsync(D[g].staging, D[0].dev, D[g].image[t], D[g].dev, words * 8, reduce_stream));
-        HIP_OK(hipEventRecord(D[g].drained[t], reduce_stream));
-        HIP_OK(mcgpu::launch_accumulate((unsigned long long*)D[0].image[t], (const unsigned long long*)D[g].staging, words, reduce_stream));
-      }
-      if (opt->write_ascii) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, reduce_stream));
-      ABI_OK(mcgpu_finalize_projection(ctx, D[0].image[t], total, cx, planes_dev[b], 1, reduce_stream));
-      HIP_OK(hipEventRecord(D[0].drained[t], reduce_stream));
-      HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, reduce_stream));
-      HIP_OK(hipEventRecord(done[b], reduce_stream));
-      // kernel time of this projection = the slowest device's launch; waiting for it also paces the host: at most two
-      // projections are in flight
+      // device 0, behind its own kernel i: the previous projection (one device: this one)
+      if (single) enqueue_reduce(i);
+      else if (i >= 1) { enqueue_reduce(i - 1); publish(i - 1); }
+      // kernel time of this projection = the slowest device's launch; waiting for it also paces the host
       float ms = 0.f;
       for (int g = 0; g < n_ctx; ++g) {
         float m = 0.f;
@@ -271,20 +303,18 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       kms[i] = ms;
       kernel_s += ms * 1e-3;
       t_last_kernel = now_s();
-      {
-        std::lock_guard<std::mutex> lk(sh.mu);
-        sh.queued = i + 1;
-        sh.cv.notify_all();
-      }
+      if (single) publish(i);
       if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
     }
+    print_skipped(count ? sim[count - 1] + 1 : 0, range);
+    if (!single && count > 0) { enqueue_reduce(count - 1); publish(count - 1); }
     writer.join();
     {
       std::lock_guard<std::mutex> lk(sh.mu);
       if (sh.abort) throw ScanError{-3, sh.error};
     }
     float repl[3] = {0.f, 0.f, 0.f};
-    if (opt->write_stacks && !shared) {
+    if (opt->write_stacks && !shared && count > 0) {
       for (int k = 0; k < 3; ++k) {
         mcgpu_stack* s = stacks[k];
         stacks[k] = nullptr;
@@ -322,26 +352,22 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   }
   if (D[0].dev >= 0) {
     (void)hipSetDevice(D[0].dev);
-    if (reduce_stream && n_ctx > 1) (void)hipStreamSynchronize(reduce_stream);
     for (int b = 0; b < 2; ++b) {
       if (planes_dev[b]) (void)hipFree(planes_dev[b]);
       if (planes_host[b]) (void)hipHostFree(planes_host[b]);
       if (image_host[b]) (void)hipHostFree(image_host[b]);
       if (done[b]) (void)hipEventDestroy(done[b]);
+      if (consumed[b]) (void)hipEventDestroy(consumed[b]);
+      for (auto& d : D)
+        if (d.landing[b]) (void)hipFree(d.landing[b]);
     }
-    for (auto& d : D) {
-      if (d.staging) (void)hipFree(d.staging);
-      for (int b = 0; b < 2; ++b)
-        if (d.drained[b]) (void)hipEventDestroy(d.drained[b]);
-    }
-    if (reduce_stream && n_ctx > 1) (void)hipStreamDestroy(reduce_stream);
   }
   for (auto& d : D) {
     if (d.dev < 0) continue;
     (void)hipSetDevice(d.dev);
     for (int b = 0; b < 2; ++b) {
       if (d.image[b]) (void)hipFree(d.image[b]);
-      if (d.tracked[b]) (void)hipEventDestroy(d.tracked[b]);
+      if (d.pushed[b]) (void)hipEventDestroy(d.pushed[b]);
     }
     if (d.stream) (void)hipStreamDestroy(d.stream);
   }

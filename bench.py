@@ -160,36 +160,39 @@ def main():
     t_load = time.perf_counter() - t_load0
 
     nz, nx = ctx.detector_shape
-    # two tally buffers: the RCCL reduce of projection i (on the communicator's own stream) overlaps the tracking of
-    # projection i + 1; a buffer is cleared again only after its reduce has been waited for
-    images = [torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda") for _ in range(2 if dist else 1)]
-    pending = [None] * len(images)
+    # N > 1: every rank tracks its history shard of G consecutive projections into G tally buffers, then ONE RCCL
+    # sum-reduce brings the G tallies to rank 0 (the reference's per-projection MPI_Reduce, MC-GPU_v1.3.cu:1019, batched:
+    # fewer, larger messages over xGMI).  The reduce is ordered between two tracking kernels on purpose: a kernel that is
+    # still running while the persistent tracking grid is dispatched fragments the CUs' register files for the whole
+    # launch and costs up to 30 % (tools/placement_probe.py), so nothing overlaps a tracking launch.
+    G = max(1, int(os.environ.get("BENCH_REDUCE_GROUP", "8"))) if dist else 1
+    images = torch.zeros((G, 4, nz, nx), dtype=torch.int64, device="cuda")
+    filled = [0]
     stream = torch.cuda.current_stream().cuda_stream
     nproj = ctx.num_projections
     seed = ctx.geti("seed")
     kernel_ms = []
 
+    def reduce_group():
+        if dist and filled[0] > 0:
+            dist.reduce(images[:filled[0]], dst=0, op=dist.ReduceOp.SUM)  # the current stream waits for it
+        filled[0] = 0
+
     def step(i, timed):
         p = (i * 149) % nproj  # spread the sampled projections over the arc
-        b = i % len(images)
-        image = images[b]
-        if pending[b] is not None:
-            pending[b].wait()  # stream-level: the clear below is ordered behind that reduce
-            pending[b] = None
+        image = images[filled[0]]
         ctx.clear(image.data_ptr(), stream)
         # disjoint history ids per rank: [rank*H, (rank+1)*H)
         ctx.launch(p, image.data_ptr(), H, mode="fast", seed=seed, first=rank * H, stream=stream)
-        if dist:
-            # per-projection detector tally -> rank 0 (RCCL over xGMI; the reference's MPI_Reduce, H.cu:1019)
-            pending[b] = dist.reduce(image, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        filled[0] += 1
+        last[0] = filled[0] - 1
         if timed:
             kernel_ms.append(ctx.last_kernel_ms())  # waits for this launch only
+        if filled[0] == G:
+            reduce_group()
 
-    def drain():
-        for b in range(len(images)):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+    last = [0]
+    drain = reduce_group
 
     for i in range(args.warmup):
         step(i, False)
@@ -209,7 +212,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    detected = int(images[(args.warmup + args.steps - 1) % len(images)].sum().item()) if rank == 0 else 0
+    detected = int(images[last[0]].sum().item()) if rank == 0 else 0
 
     if rank == 0:
         total_hist = float(H) * world * args.steps
@@ -223,7 +226,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"catphan604_{args.voxels}cube_1mm_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
                        "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
-                       "parallelism": f"history-sharded x{world}, RCCL sum-reduce of the detector tally per projection (overlapped with the next projection)",
+                       "parallelism": f"history-sharded x{world}" + (f", one RCCL sum-reduce of the detector tallies per {G} projections" if dist else ""),
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
                        "volume_bytes": ctx.geti("volume_bytes_device"), "per_gpu_value": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

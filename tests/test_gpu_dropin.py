@@ -46,6 +46,34 @@ def test_executable_compat_matches_oracle_and_log_contract(engine, tmp_path):
             seed = engine.advance_seed(1, total, seed)  # GPU-build seed stepping between projections (MC-GPU_v1.3.cu:869)
 
 
+def test_executable_skips_projections_outside_the_angular_roi(engine, tmp_path):
+    """MC-GPU_v1.3.cu:670-677: projections outside "ANGLES OF INTEREST" are not simulated, write no file, and do not
+    advance the seed (:869 sits behind the `continue`)."""
+    inp = cases.build_case("catphan64_ct", tmp_path, n_histories=19200 * 5)
+    text = inp.read_text()
+    assert "0.0 5000.0  # ANGLES OF INTEREST" in text
+    inp.write_text(text.replace("0.0 5000.0  # ANGLES OF INTEREST", "300.0 500.0  # ANGLES OF INTEREST"))
+    res = subprocess.run([str(engine.EXE_PATH), str(inp), "--mode", "compat", "--stacks", "--crop", "0"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and not re.search("(?i)error", res.stdout), res.stdout[-2000:]
+    assert [int(a) for a in re.findall(r"Skipping projection #(\d+) of 4", res.stdout)] == [1, 4]
+    assert [int(a) for a in re.findall(r"Simulating Projection (\d+) of 4", res.stdout)] == [2, 3]
+    files = sorted(f.name for f in tmp_path.iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
+    assert files == ["projection_360.000000deg", "projection_450.000000deg"]
+    assert engine.stack_read(tmp_path / "projections_total.mha").shape[0] == 2
+    with engine.create(inp, device=-1) as ctx:
+        T = parity.tables_from_context(ctx)
+        nz, nx = ctx.detector_shape
+        batches, hpt, total = ctx.reference_shape()
+        det = ctx.host_table("detector_data", "<f4")
+        norm = 0.01 * float(det[19]) * float(det[20]) / total
+        seed = 42
+        for p, name in zip((1, 2), files):
+            img, _ = T.track(p, seed, 0, batches, hpt, ol.MATH_PORTABLE, n_threads=4)
+            want = np.flip((img.reshape(4, nz, nx).astype(np.float64) * norm).transpose(1, 2, 0), axis=0)
+            assert np.allclose(_read_like_reference(tmp_path / name, nz, nx, np.float64), want, rtol=0, atol=0.51e-8)
+            seed = engine.advance_seed(1, total, seed)
+
+
 def test_executable_reports_errors_like_the_reference(engine, tmp_path):
     res = subprocess.run([str(engine.EXE_PATH), str(tmp_path / "missing.in")], capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and re.search("(?i)error", res.stdout)
