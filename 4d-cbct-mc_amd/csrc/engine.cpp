@@ -289,7 +289,23 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       const Float3& b = H.mat.b[(size_t)i * kMaxMaterials + m];
       r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
       r[6] = H.mat.pmax[(size_t)(i + 1) * kMaxMaterials + m];
-      r[7] = 0.f;
+      {
+        // FAST Compton sampler (track_common.inc: compton_angle_trial): upper bound of s0 = S(E, theta = pi) =
+        // sum_i f_i n_i(E, cdt = 2) (K.cu:1299-1314) over this energy bin.  Every n_i grows with E and shells only switch
+        // on, so the value at the bin's upper edge bounds the bin; the margin covers float rounding on the device.
+        const double E = (double)H.mat.e0 + (double)(i + 1) / (double)H.mat.ide, mc2 = 510998.918;
+        double s0 = 0.0;
+        for (int k = 0; k < std::min(H.mat.noscco[m], kMaxShells); ++k) {
+          const double U = H.mat.uico[m + k * kMaxMaterials], J = H.mat.fj0[m + k * kMaxMaterials], f = H.mat.fco[m + k * kMaxMaterials];
+          if (!(U < E)) continue;
+          const double aux = E * (E - U) * 2.0;
+          const double pz = J * (aux - U * mc2) / (std::sqrt(aux + aux + U * U) * mc2);
+          const double q = 0.70710678118654502 + std::fabs(pz) * 1.4142135623731;
+          const double n = 0.5 * std::exp(0.5 - q * q);
+          s0 += f * (pz > 0.0 ? 1.0 - n : n);
+        }
+        r[7] = (float)(s0 * 1.0001);
+      }
     }
   D.woodcock = D.put(wood);
   D.mfp = D.put(rec);
@@ -658,8 +674,8 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       {  // FAST scheduling knobs live in TrackCold; the environment may change them between launches (tuning sweeps)
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         TrackCold& ch = D.cold_host;
-        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", 40), env_int("MCGPU_THRESH_RAYLEIGH", 12), env_int("MCGPU_THRESH_NEW", 40),
-                              std::max(1, env_int("MCGPU_FLYABLE_LOW", 16)), std::max(1, env_int("MCGPU_SWAP_BATCH", 12))};
+        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", 24), env_int("MCGPU_THRESH_RAYLEIGH", 8), env_int("MCGPU_THRESH_NEW", 40),
+                              std::max(1, env_int("MCGPU_FLYABLE_LOW", 12)), std::max(1, env_int("MCGPU_SWAP_BATCH", 24))};
         if (ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
             ch.swap_batch != want5[4]) {
           ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];

@@ -280,10 +280,11 @@ class Context:
 
     def scheduler_stats(self, reset: bool = True) -> dict:
         """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""
-        out = (C.c_ulonglong * 16)()
-        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 16, int(reset)))
+        out = (C.c_ulonglong * 24)()
+        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 24, int(reset)))
         names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
-                 "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight")
+                 "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight",
+                 "compton_angle_trips", "compton_angle_trials", "compton_shell_trips", "compton_shell_trials", "spare20", "spare21", "spare22", "spare23")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

@@ -1,0 +1,27 @@
+"""Kernel-time sweep of the FAST scheduler knobs on the bench workload (GPU).
+usage: tune.py "tC,tR,tN,flyable_low,swap_batch" ...   (5 launches of 1e8 histories each, mean kernel ms)"""
+import os, sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, torch, cases
+eng = cases.pkg.engine
+KEYS = ("MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH")
+ctx = eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0)
+nz, nx = ctx.detector_shape
+image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+H = int(float(os.environ.get("TUNE_HIST", "1e8")))
+res = []
+for cfg in sys.argv[1:]:
+    for k in KEYS:
+        os.environ.pop(k, None)
+    for k, v in zip(KEYS, [x for x in cfg.split(",") if x]):
+        os.environ[k] = v
+    ms = []
+    for i in range(7):
+        ctx.clear(image.data_ptr(), stream)
+        ctx.launch((i * 149) % ctx.num_projections, image.data_ptr(), H, mode="fast", seed=1, first=0, stream=stream)
+        ms.append(ctx.last_kernel_ms())
+    res.append((float(np.mean(ms[2:])), cfg))
+    print(f"{cfg:24s} {np.mean(ms[2:]):.3f} ms  (min {np.min(ms[2:]):.3f})", flush=True)
+print("best:", sorted(res)[:5])
+ctx.close()
