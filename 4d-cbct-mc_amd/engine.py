@@ -284,7 +284,7 @@ class Context:
         _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 24, int(reset)))
         names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
                  "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight",
-                 "compton_angle_trips", "compton_angle_trials", "compton_shell_trips", "compton_shell_trials", "spare20", "spare21", "spare22", "spare23")
+                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "lanes_idle", "lanes_both_flyable")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

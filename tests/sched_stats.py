@@ -28,12 +28,11 @@ with eng.create(inp, device=0) as ctx:
                           "sched_points_per_hist": round(s["scheduling_points"] / done, 4),
                           "take": [round(s["take_lanes"] / max(s["take_rounds"], 1), 1), round(s["take_rounds"] / done, 5)],
                           "drain_frac": round(s["drain_points"] / max(s["scheduling_points"], 1), 3),
-                          "compton_loops": {"angle_trips_per_round": round(s["compton_angle_trips"] / max(s["compton_rounds"], 1), 2),
-                                            "angle_trials_per_event": round(s["compton_angle_trials"] / max(s["compton_lanes"], 1), 2),
-                                            "angle_lanes_per_trip": round(s["compton_angle_trials"] / max(s["compton_angle_trips"], 1), 1),
-                                            "shell_trips_per_round": round(s["compton_shell_trips"] / max(s["compton_rounds"], 1), 2),
-                                            "shell_trials_per_event": round(s["compton_shell_trials"] / max(s["compton_lanes"], 1), 2),
-                                            "shell_lanes_per_trip": round(s["compton_shell_trials"] / max(s["compton_shell_trips"], 1), 1)},
+                          "compton_trials": {"angle_lanes_per_round": round(s["compton_angle_lanes"] / max(s["compton_rounds"], 1), 1),
+                                             "shell_lanes_per_round": round(s["compton_shell_lanes"] / max(s["compton_rounds"], 1), 1),
+                                             "done_per_round": round(s["compton_done_lanes"] / max(s["compton_rounds"], 1), 1)},
+                          "pool_after_sched_point": {k: round(s[k] / max(s["scheduling_points"], 1), 1) for k in
+                                                     ("pool_flyable", "pool_wants_new", "pool_compton", "lanes_idle", "lanes_both_flyable")},
                           "cycles_per_hist": {k[7:]: round(s[k] / done, 1) for k in ("cycles_flight", "cycles_compton", "cycles_rayleigh", "cycles_new")},
                           "wave_cycles_per_hist_total(100MHz ticks?)": round(secs_stats * 1e8 * 6144 / done, 1),
                           "blocks_per_cu": ctx.geti("blocks_per_cu"), "lds": ctx.geti("lds_bytes_fast")}))
