@@ -674,7 +674,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       {  // FAST scheduling knobs live in TrackCold; the environment may change them between launches (tuning sweeps)
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         TrackCold& ch = D.cold_host;
-        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", 24), env_int("MCGPU_THRESH_RAYLEIGH", 8), env_int("MCGPU_THRESH_NEW", 40),
+        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", 24), env_int("MCGPU_THRESH_RAYLEIGH", 8), env_int("MCGPU_THRESH_NEW", 36),
                               std::max(1, env_int("MCGPU_FLYABLE_LOW", 12)), std::max(1, env_int("MCGPU_SWAP_BATCH", 24))};
         if (ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
             ch.swap_batch != want5[4]) {
