@@ -280,11 +280,12 @@ class Context:
 
     def scheduler_stats(self, reset: bool = True) -> dict:
         """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""
-        out = (C.c_ulonglong * 24)()
-        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 24, int(reset)))
+        out = (C.c_ulonglong * 28)()
+        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 28, int(reset)))
         names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
                  "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight",
-                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "lanes_idle", "lanes_both_flyable")
+                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "lanes_idle", "lanes_both_flyable",
+                 "iter_with_voxel_load", "voxel_load_lanes", "iter_with_sigma_load", "sigma_load_lanes")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

@@ -11,7 +11,7 @@ side = torch.cuda.Stream()
 main = torch.cuda.current_stream().cuda_stream
 dev_big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
 H = int(1e8)
-NT = 24 + 3 * 16384
+NT = 28 + 3 * 16384
 
 def run(name, interfere):
     for rep in range(3):
@@ -26,7 +26,7 @@ def run(name, interfere):
         ms = ctx.last_kernel_ms()
         torch.cuda.synchronize()
         ctx.lib.mcgpu_scheduler_stats_ex(ctx.h, out, NT, 0)
-    a = np.frombuffer(out, dtype=np.uint64)[24:].reshape(-1, 3)
+    a = np.frombuffer(out, dtype=np.uint64)[28:].reshape(-1, 3)
     a = a[a[:, 1] != 0]
     hw = (a[:, 0] & 0xffffffff).astype(np.int64); xcc = (a[:, 0] >> 32).astype(np.int64) & 0xf
     wave, simd, cu, sh, se = hw & 0xf, (hw >> 4) & 3, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
