@@ -45,6 +45,9 @@ struct LdsLayout {
   int brick;                 // u8[brick_bytes]
   int dose_mat;              // u64[25][2]: per-workgroup material-dose accumulators, flushed at kernel end
   int slots;                 // u32[kSlotWords][kPoolBlockThreads] (FAST kernel only)
+  // FAST kernel only: brackets of the total cross section per (coarse energy bin, material), TrackArgs::sig_shift >= 0
+  int sig_mid;               // fp16[ncoarse * nmat]: centre of [min, max] of mfp_tot over the coarse bin
+  int sig_w;                 // float[ncoarse]: relative half width that covers every material of the bin
   int total;                 // bytes
 };
 
@@ -60,6 +63,8 @@ struct TrackCold {
   const float *espc, *cutoff;
   const short* alias;
   const unsigned char* bricks;  // brick grid, two 4-bit codes per byte (u8 volumes only)
+  const unsigned short* sig_mid;  // staging sources of LdsLayout::sig_mid / sig_w (null when the brackets are off)
+  const float* sig_w;
   int brick_palette[16];        // palette index of brick code c (c < 15)
   // dose tallies (K.cu:418-443, :1547-1563); buffers live for the whole simulation (all projections accumulate)
   unsigned long long* dose_voxels;     // ulonglong2 {Edep * 100, Edep^2} per ROI voxel, x fastest; null = tally off
@@ -95,6 +100,7 @@ struct TrackArgs {
   const float* woodcock;  // float2[num_values]
   const float* mfp;       // 8 floats per (bin*nmat + mc)
   const float* mfp_tot;   // float2 {a_tot, b_tot} per (bin*nmat + mc): the only cross section a flight step needs (FAST)
+  int sig_shift;          // FAST: coarse energy bin = bin >> sig_shift for the LDS brackets of mfp_tot; -1 = no brackets
   const TrackCold* cold;
   int nbins;
   // pose of this projection (device-resident arrays of all projections, uploaded once)

@@ -72,6 +72,10 @@ struct DeviceModel {
   unsigned long long* work_counter = nullptr;  // history-id dispenser of the FAST kernel
   unsigned long long* scratch_image = nullptr;  // device tally of mcgpu_run_projection (allocated on first use)
   float *woodcock = nullptr, *mfp = nullptr, *mfp_tot = nullptr;
+  unsigned short* sig_mid = nullptr;  // cross-section brackets (FAST flight step), see upload_model
+  float* sig_w = nullptr;
+  int sig_shift = -1, sig_coarse = 0;
+  std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
   float *fco = nullptr, *uico = nullptr, *fj0 = nullptr;
@@ -313,6 +317,12 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     std::vector<float> tot(2 * (size_t)nv * nmat);
     for (size_t k = 0; k < (size_t)nv * nmat; ++k) { tot[2 * k] = rec[8 * k]; tot[2 * k + 1] = rec[8 * k + 3]; }
     D.mfp_tot = D.put(tot);
+    // Brackets of the total cross section for the FAST flight step: per (coarse energy bin = 2^shift table bins,
+    // material) the centre of [min, max] of a_tot + b_tot * E over the coarse bin as fp16, and per coarse bin one
+    // relative half width covering every material.  A step whose random number falls outside
+    // [1 - m*hi, 1 - m*lo) is decided from LDS alone; only the narrow band in between fetches the exact value, so the
+    // decisions are those of the exact test.  The LDS image takes the finest table that still leaves two workgroups per CU.
+    D.sig_tot_host = tot;
   }
   std::vector<float> xco(kRayleighPoints * nmat), pco(xco), aco(xco), bco(xco);
   std::vector<unsigned char> itl(kRayleighPoints * nmat), itu(itl);
@@ -362,7 +372,62 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.dose_mat = take(2 * kMaxMaterials * 8, 16);
     Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
     take(kSlotWords * kPoolBlockThreads * 4, 16);
+    Y.sig_mid = Y.sig_w = off;
+    D.sig_shift = -1;
+    if (!getenv("MCGPU_NO_BRACKETS") && nmat > 0) {
+      const int budget = 160 * 1024 / 2;  // two 1024-thread workgroups per CU
+      for (int shift = 6; shift <= 12; ++shift) {
+        const int nc = (nv + (1 << shift) - 1) >> shift;
+        const int need = (off + 15) / 16 * 16 + (nc * nmat * 2 + 15) / 16 * 16 + (nc * 4 + 15) / 16 * 16;
+        if (need > budget) continue;
+        D.sig_shift = shift;
+        D.sig_coarse = nc;
+        Y.sig_mid = take(nc * nmat * 2, 16);
+        Y.sig_w = take(nc * 4, 16);
+        break;
+      }
+    }
     Y.total = (off + 15) / 16 * 16;
+  }
+  if (D.sig_shift >= 0) {
+    const int nc = D.sig_coarse, shift = D.sig_shift;
+    auto to_half = [](float f) -> unsigned short {  // round to nearest even; inputs are positive normal numbers
+      uint32_t x; memcpy(&x, &f, 4);
+      const int e = (int)((x >> 23) & 0xFF) - 127 + 15;
+      uint32_t m = x & 0x7FFFFF;
+      if (e <= 0) return 0;
+      if (e >= 31) return 0x7BFF;
+      uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+      const uint32_t rem = m & 0x1FFF;
+      if (rem > 0x1000 || (rem == 0x1000 && (h & 1))) ++h;
+      return (unsigned short)std::min<uint32_t>(h, 0x7BFF);
+    };
+    auto from_half = [](unsigned short h) -> double { return std::ldexp((double)((h & 0x3FF) | 0x400), (int)(h >> 10) - 25); };
+    std::vector<unsigned short> mid((size_t)nc * nmat, 0);
+    std::vector<float> wv(nc, 0.f);
+    const double e0 = H.mat.e0, ide = H.mat.ide;
+    for (int c = 0; c < nc; ++c) {
+      double wmax = 0.0;
+      for (int mc = 0; mc < nmat; ++mc) {
+        double lo = 1e300, hi = -1e300;
+        for (int i = c << shift; i < std::min(nv, (c + 1) << shift); ++i) {
+          const double a = D.sig_tot_host[2 * ((size_t)i * nmat + mc)], b = D.sig_tot_host[2 * ((size_t)i * nmat + mc) + 1];
+          // the kernel evaluates a + b * E for E in [E_i, E_{i+1}) (one table bin; a little beyond for float rounding)
+          const double ea = e0 + (i - 0.01) / ide, eb = e0 + (i + 1.01) / ide;
+          lo = std::min(lo, std::min(a + b * ea, a + b * eb));
+          hi = std::max(hi, std::max(a + b * ea, a + b * eb));
+        }
+        if (!(lo > 0.0)) lo = std::min(1e-30, hi > 0.0 ? hi : 1e-30);
+        const unsigned short hbits = to_half((float)(0.5 * (lo + hi)));
+        mid[(size_t)c * nmat + mc] = hbits;
+        const double m = from_half(hbits);
+        if (hbits == 0 || hbits == 0x7BFF || !(m > 0.0)) { wmax = 1e30; continue; }  // not representable: the band is everything
+        wmax = std::max(wmax, std::max((hi - m) / m, (m - lo) / m));
+      }
+      wv[c] = (float)std::min(wmax * 1.001 + 1e-5, 1e30);
+    }
+    D.sig_mid = D.put(mid);
+    D.sig_w = D.put(wv);
   }
   D.num_spectrum_bins = H.spectrum.num_bins;
   {
@@ -372,6 +437,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     cold.fco = D.fco; cold.uico = D.uico; cold.fj0 = D.fj0; cold.noscco = D.noscco;
     cold.espc = D.espc; cold.cutoff = D.cutoff; cold.alias = D.alias;
     cold.bricks = D.bricks;
+    cold.sig_mid = D.sig_mid; cold.sig_w = D.sig_w;
     for (int c = 0; c < 16; ++c) cold.brick_palette[c] = D.brick_palette[c];
     // dose tallies (read_input :1868-1893, init_CUDA_device :2636-2657,2694-2720)
     const SimConfig& cfg = H.cfg;
@@ -427,7 +493,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   require((long long)A.nx * A.ny < (1LL << 24) && (long long)H.voxels.count() < (1LL << 31), -2,
           "!!ERROR!! voxel grid too large for the 32-bit voxel index of the kernel");
   A.e0 = H.mat.e0; A.ide = H.mat.ide; A.num_values = H.mat.num_values; A.nmat = D.nmat;
-  A.woodcock = D.woodcock; A.mfp = D.mfp; A.mfp_tot = D.mfp_tot;
+  A.woodcock = D.woodcock; A.mfp = D.mfp; A.mfp_tot = D.mfp_tot; A.sig_shift = D.sig_shift;
   A.cold = D.cold;
   A.nbins = H.spectrum.num_bins;
   A.src = D.src_all + p; A.det = D.det_all + p;
@@ -564,6 +630,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "bricks_exterior") *value = ctx->dev.bricks_exterior;
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
+  else if (k == "sigma_bracket_shift") *value = ctx->dev.sig_shift;
   else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots;
   else return set_error(-2, std::string("unknown integer key: ") + key);
   return 0;
