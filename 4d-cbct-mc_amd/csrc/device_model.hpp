@@ -30,6 +30,7 @@ enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
+constexpr int kQueueRecordsPerBlock = 2048;  // event-queue kernel: history records per 1024-thread workgroup
 constexpr int kSlotWords = 14;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kNumStats = 28;             // scheduler counters of the diagnostic build
 constexpr int kWaveTrace = 16384;         // diagnostic build: {hardware id, first and last clock} of up to this many waves follow the counters
@@ -48,6 +49,9 @@ struct LdsLayout {
   // FAST kernel only: brackets of the total cross section per (coarse energy bin, material), TrackArgs::sig_shift >= 0
   int sig_mid;               // fp16[ncoarse * nmat]: centre of [min, max] of mfp_tot over the coarse bin
   int sig_w;                 // float[ncoarse]: relative half width that covers every material of the bin
+  // event-queue kernel only (its own layout: `slots` then holds kQueueRecordsPerBlock records)
+  int qctl;                  // u32 head[8], tail[8], exhausted flag
+  int qring;                 // u16[5][kQueueRecordsPerBlock]
   int total;                 // bytes
 };
 

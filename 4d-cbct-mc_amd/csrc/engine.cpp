@@ -24,6 +24,7 @@ hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t st
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
 int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
+hipError_t launch_track_queue(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 hipError_t launch_warp(int nx, int ny, int nz, const unsigned char* mat, const float* dens, const float* dvf, unsigned char default_mat,
@@ -59,6 +60,8 @@ struct DeviceModel {
   int num_spectrum_bins = 0;
   int shell_first[kMaxMaterials] = {0};
   LdsLayout lds;
+  LdsLayout lds_queue;      // layout of the event-queue kernel (total 0 = does not fit: use the lane-bound kernel)
+  int sig_shift_queue = -1;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
   TrackCold cold_host;            // its host image (re-uploaded when a tuning knob changes)
   unsigned long long* dose_voxels = nullptr;     // ulonglong2 per ROI voxel (null: tally off)
@@ -388,6 +391,23 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       }
     }
     Y.total = (off + 15) / 16 * 16;
+    // event-queue kernel: same tables, then kQueueRecordsPerBlock records, the brackets, queue counters and rings
+    LdsLayout Q = Y;
+    int qoff = Y.slots;
+    auto qtake = [&](int bytes, int align) { qoff = (qoff + align - 1) / align * align; const int at = qoff; qoff += bytes; return at; };
+    qtake(kSlotWords * kQueueRecordsPerBlock * 4, 16);
+    Q.qctl = qtake(32 * 4, 16);
+    Q.qring = qtake(5 * kQueueRecordsPerBlock * 2, 16);
+    Q.sig_mid = Q.sig_w = qoff;
+    D.sig_shift_queue = -1;
+    if (D.sig_shift >= 0) {  // the same table as the lane-bound kernel, if it fits here too
+      const int nc = D.sig_coarse;
+      const int need = (qoff + 15) / 16 * 16 + (nc * nmat * 2 + 15) / 16 * 16 + (nc * 4 + 15) / 16 * 16;
+      if (need <= 160 * 1024) { Q.sig_mid = qtake(nc * nmat * 2, 16); Q.sig_w = qtake(nc * 4, 16); D.sig_shift_queue = D.sig_shift; }
+    }
+    Q.total = (qoff + 15) / 16 * 16;
+    if (Q.total > 160 * 1024) Q.total = 0;
+    D.lds_queue = Q;
   }
   if (D.sig_shift >= 0) {
     const int nc = D.sig_coarse, shift = D.sig_shift;
@@ -758,7 +778,15 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         A.stats = D.stats;
         HIP_TRY(launch_track_stats(A, (int)std::min(want, resident), stream));
       } else {
-        HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
+        // MCGPU_FAST_KERNEL=queue: the event-queue organisation (track_pool.inc), one workgroup per CU
+        const char* fk = getenv("MCGPU_FAST_KERNEL");
+        if (fk && !strcmp(fk, "queue") && D.lds_queue.total > 0) {
+          A.lds = D.lds_queue;
+          A.sig_shift = D.sig_shift_queue;
+          HIP_TRY(launch_track_queue(A, (int)std::min<unsigned long long>(want, (unsigned long long)D.num_cus), stream));
+        } else {
+          HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
+        }
       }
     }
   }
