@@ -783,6 +783,10 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         if (fk && !strcmp(fk, "queue") && D.lds_queue.total > 0) {
           A.lds = D.lds_queue;
           A.sig_shift = D.sig_shift_queue;
+          if (getenv("MCGPU_QUEUE_STATS")) {  // diagnostics: counters of the queue kernel in the scheduler-stats buffer
+            if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats + 3 * kWaveTrace, 0ULL));
+            A.stats = D.stats;
+          }
           HIP_TRY(launch_track_queue(A, (int)std::min<unsigned long long>(want, (unsigned long long)D.num_cus), stream));
         } else {
           HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));

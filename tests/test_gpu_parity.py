@@ -145,6 +145,36 @@ def test_fast_image_is_independent_of_the_schedule(gpu_engine, case_dir, monkeyp
                 monkeypatch.delenv(k)
 
 
+def test_fast_cross_section_brackets_decide_like_the_exact_table(gpu_engine, case_dir, monkeypatch):
+    """The flight step decides most virtual/real tests from the LDS brackets of the total cross section (track_pool.inc:
+    flight_step) and fetches the exact value only inside the bracket: the decisions -- hence every tally word -- must be
+    those of the exact table alone (MCGPU_NO_BRACKETS)."""
+    imgs = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MCGPU_NO_BRACKETS", "1")
+        for case in ("catphan64_ct", "graded_u16"):
+            with gpu_engine.create(case_dir(case), device=0) as ctx:
+                assert (ctx.geti("sigma_bracket_shift") < 0) == off
+                imgs[(case, off)] = ctx.run_projection(1, 1_000_000, mode="fast", seed=3)[0]
+    for case in ("catphan64_ct", "graded_u16"):
+        assert np.array_equal(imgs[(case, False)], imgs[(case, True)]), case
+        assert imgs[(case, False)].sum() > 0
+
+
+def test_fast_event_queue_kernel_equals_lane_bound_kernel(gpu_engine, case_dir, monkeypatch):
+    """MCGPU_FAST_KERNEL=queue runs the same per-history arithmetic from workgroup-level queues (track_pool.inc:
+    track_queue_kernel): the tally must be identical word for word, including the dose tallies."""
+    for case, n in (("catphan64_ct", 600_000), ("water", 100_000), ("catphan64_dose", 300_000)):
+        with gpu_engine.create(case_dir(case), device=0) as ctx:
+            ref = ctx.run_projection(0, n, mode="fast", seed=9)[0]
+            monkeypatch.setenv("MCGPU_FAST_KERNEL", "queue")
+            for rep in range(2):
+                img = ctx.run_projection(0, n, mode="fast", seed=9)[0]
+                assert np.array_equal(img, ref), (case, rep)
+            monkeypatch.delenv("MCGPU_FAST_KERNEL")
+
+
 def test_fast_exterior_hop_is_statistically_equivalent_to_delta_tracking(gpu_engine, case_dir, monkeypatch):
     """The analytic crossing of the homogeneous exterior (track_pool.inc: exterior_hop) against plain Woodcock tracking
     everywhere (MCGPU_NO_EXTERIOR): two independent estimates of the same images."""
