@@ -25,6 +25,7 @@ hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stre
 int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_track_queue(const TrackArgs& args, int blocks, hipStream_t stream);
+hipError_t launch_track_pool3(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 hipError_t launch_warp(int nx, int ny, int nz, const unsigned char* mat, const float* dens, const float* dvf, unsigned char default_mat,
@@ -60,6 +61,8 @@ struct DeviceModel {
   int num_spectrum_bins = 0;
   int shell_first[kMaxMaterials] = {0};
   LdsLayout lds;
+  LdsLayout lds_pool3;      // three histories per lane: two slot planes (total 0 = does not fit)
+  int sig_shift_pool3 = -1;
   LdsLayout lds_queue;      // layout of the event-queue kernel (total 0 = does not fit: use the lane-bound kernel)
   int sig_shift_queue = -1;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
@@ -408,6 +411,20 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Q.total = (qoff + 15) / 16 * 16;
     if (Q.total > 160 * 1024) Q.total = 0;
     D.lds_queue = Q;
+    // three histories per lane: two slot planes behind the tables, then the brackets
+    LdsLayout P3 = Y;
+    int poff = Y.slots + 2 * kSlotWords * kPoolBlockThreads * 4;
+    P3.sig_mid = P3.sig_w = poff;
+    D.sig_shift_pool3 = -1;
+    if (D.sig_shift >= 0) {
+      const int nc = D.sig_coarse;
+      P3.sig_mid = (poff + 15) / 16 * 16; poff = P3.sig_mid + nc * nmat * 2;
+      P3.sig_w = (poff + 15) / 16 * 16; poff = P3.sig_w + nc * 4;
+      D.sig_shift_pool3 = D.sig_shift;
+    }
+    P3.total = (poff + 15) / 16 * 16;
+    if (P3.total > 160 * 1024) P3.total = 0;
+    D.lds_pool3 = P3;
   }
   if (D.sig_shift >= 0) {
     const int nc = D.sig_coarse, shift = D.sig_shift;
@@ -788,6 +805,10 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
             A.stats = D.stats;
           }
           HIP_TRY(launch_track_queue(A, (int)std::min<unsigned long long>(want, (unsigned long long)D.num_cus), stream));
+        } else if (fk && !strcmp(fk, "pool3") && D.lds_pool3.total > 0) {
+          A.lds = D.lds_pool3;
+          A.sig_shift = D.sig_shift_pool3;
+          HIP_TRY(launch_track_pool3(A, (int)std::min<unsigned long long>(want, (unsigned long long)D.num_cus), stream));
         } else {
           HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
         }

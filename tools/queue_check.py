@@ -15,7 +15,7 @@ for name, n in small:
         for p in range(min(ctx.num_projections, 2)):
             os.environ.pop("MCGPU_FAST_KERNEL", None)
             a, _, da = ctx.run_projection(p, n, mode="fast", seed=42 + p)
-            os.environ["MCGPU_FAST_KERNEL"] = "queue"
+            os.environ["MCGPU_FAST_KERNEL"] = os.environ.get("QCHK_KERNEL", "queue")
             b, _, db = ctx.run_projection(p, n, mode="fast", seed=42 + p)
             same = np.array_equal(a, b)
             ok &= same
