@@ -198,26 +198,30 @@ def test_fast_exterior_hop_is_statistically_equivalent_to_delta_tracking(gpu_eng
     assert np.mean(np.abs(z[mask]) > 3.0) < 0.01 and np.abs(z[mask]).max() < 6.0 and abs(z[mask].mean()) < 0.1
 
 
-def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir):
-    """FAST vs tests/golden/stat_catphan64.npz: 16 x 4e7 histories of the CPU oracle in its
-    reference-identical mode -> per-block mean and run-to-run variance.  With 6.4e8 GPU histories the comparison resolves
-    a bias of a few hundredths of a sigma per 3x3-pixel block; tolerance: Student-t tails of a 16-run variance estimate."""
+@pytest.mark.parametrize("case,projection,fixture", [("catphan64", 0, "stat_catphan64.npz"), ("slab_angles", 1, "stat_slab_angles_p1.npz")])
+def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, case, projection, fixture):
+    """FAST vs tests/golden/stat_*.npz: 16 independent runs of the CPU oracle in its
+    reference-identical mode -> per-block mean and run-to-run variance (catphan64: 16 x 4e7 histories, straight projection;
+    slab_angles projection 1: 16 x 2.5e7, rotated source/detector at 300.5 degrees through water, bone and Teflon, i.e. the
+    many-shell Compton class and the rotation branches of source and tally).  With as many GPU histories the comparison
+    resolves a bias of a few hundredths of a sigma per 3x3-pixel block; tolerance: Student-t tails of a 16-run variance
+    estimate."""
     import golden_util as gu
-    g = gu.load("stat_catphan64.npz")
+    g = gu.load(fixture)
     mean, var_ref = g["mean"].astype(np.float64), g["var_of_mean"].astype(np.float64)
     n_ref = int(g["histories_per_run"]) * int(g["runs"])
     n_gpu = n_ref
-    with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
+    with gpu_engine.create(case_dir(case), device=0) as ctx:
         img = np.zeros((4,) + ctx.detector_shape, dtype=np.float64)
         for k in range(4):  # four launches with different seeds: independent histories
-            part, _, done = ctx.run_projection(0, n_gpu // 4, mode="fast", seed=100 + k)
+            part, _, done = ctx.run_projection(projection, n_gpu // 4, mode="fast", seed=100 + k)
             img += part
         nz, nx = img.shape[1:]
         b = img[:, : nz // 3 * 3, : nx // 3 * 3].reshape(4, nz // 3, 3, nx // 3, 3).sum(axis=(2, 4)) / (n_gpu // 4 * 4)
     mask = var_ref > 0
     mask &= mean * n_ref / 6.0e6 > 50  # at least ~50 detected photons behind the reference mean
     z = (b[mask] - mean[mask]) / np.sqrt(var_ref[mask] * (1.0 + n_ref / n_gpu))
-    assert mask.sum() > 3000
+    assert mask.sum() > 2000
     assert np.mean(np.abs(z) > 3.0) < 0.02 and np.abs(z).max() < 8.0, (np.mean(np.abs(z) > 3.0), np.abs(z).max())
     assert abs(z.mean()) < 5.0 / np.sqrt(mask.sum()), z.mean()  # no systematic offset
     for k in range(4):  # detected energy per history per class
