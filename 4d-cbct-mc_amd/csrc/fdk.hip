@@ -1,0 +1,372 @@
+// fdk.hip -- circular cone-beam FDK reconstruction for MI355X (what `rtkfdk --hardware cuda` does for
+// the reference, cbctmc/reconstruction/reconstruction.py:22-69, reconstructors.py).  RTK itself is an un-vendored
+// third-party dependency of the reference; the algorithm and RTK's geometry conventions are restated in oracle/fdk_oracle.py
+// (parity unpinned against RTK, pinned by analytic phantoms) and implemented here as four kernels:
+//   weight      : water pre-correction polynomial, cosine weight, displaced-detector (half-fan) weight, zero padding of the
+//                 short side to a detector symmetric about the central ray                                     (streaming)
+//   ramp_rows   : linear convolution of every detector row with the (Hann-apodised) ramp kernel, row and kernel in LDS,
+//                 four outputs per thread from a sliding register window: 0.5 LDS reads per FMA                 (LDS/VALU)
+//   smooth_cols : --hannY low-pass along v (3 taps for 1.0)                                                     (streaming)
+//   backproject : voxel-driven, bilinear; a thread owns one (x, z) column of the volume, precomputes everything that does
+//                 not depend on y for a batch of 16 projections in registers, then walks y: 4 loads + 10 flops per update;
+//                 the filtered projections of a batch (3 MB each) stay L2-resident                              (L2 gather)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcgpu_amd.h"
+
+extern "C" void mcgpu_set_last_error_(const char* message);
+
+namespace {
+
+constexpr int kBatch = 16;  // projections per back-projection launch
+
+struct ProjParam {  // per projection, wave-uniform in the kernels
+  float c, s;       // cos / sin of the gantry angle
+  float off_x, off_y;
+};
+
+// in: [n][nv][nu] raw line integrals; out: [n][nv][nu_p] weighted rows, padded with pad_l zero columns on the left (and zeros on the
+// right) so that an off-centre detector becomes symmetric about the central ray (RTK: DisplacedDetectorImageFilter)
+__global__ void weight_kernel(const float* __restrict__ in, float* __restrict__ out, int nu, int nv, int n, int nu_p, int pad_l, float du, float dv,
+                              float u0, float v0, float sdd, const ProjParam* __restrict__ pp, const float* __restrict__ w_dis /*[n][nu]*/,
+                              const float* __restrict__ wpc, int n_wpc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n * nv * nu_p;
+  if (i >= total) return;
+  const int ip = (int)(i % nu_p), iv = (int)((i / nu_p) % nv), k = (int)(i / ((size_t)nu_p * nv));
+  const int iu = ip - pad_l;
+  float v = 0.f;
+  if (iu >= 0 && iu < nu) {
+    v = in[((size_t)k * nv + iv) * nu + iu];
+    if (n_wpc > 0) {  // rtkfdk --wpc: sum_k c_k p^k
+      float acc = 0.f, pw = 1.f;
+      for (int j = 0; j < n_wpc; ++j) { acc += wpc[j] * pw; pw *= v; }
+      v = acc;
+    }
+    const float up = u0 + du * iu + pp[k].off_x, vp = v0 + dv * iv + pp[k].off_y;
+    v *= sdd / sqrtf(sdd * sdd + up * up + vp * vp) * w_dis[(size_t)k * nu + iu];
+  }
+  out[i] = v;
+}
+
+// out[row][i] = scale * sum_j in[row][j] * h[i - j + nu - 1];  one block per row, 256 threads, 4 consecutive outputs per thread
+__global__ __launch_bounds__(256) void ramp_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ h, int nu, float scale) {
+  extern __shared__ float lds[];
+  float* row = lds;             // [nu]
+  float* hk = lds + nu;         // [2 nu - 1 + 3] (padded with zeros so that the window may run past the ends)
+  const size_t base = (size_t)blockIdx.x * nu;
+  for (int i = threadIdx.x; i < nu; i += blockDim.x) row[i] = in[base + i];
+  for (int i = threadIdx.x; i < 2 * nu + 2; i += blockDim.x) hk[i] = (i < 2 * nu - 1) ? h[i] : 0.f;
+  __syncthreads();
+  for (int i0 = 4 * threadIdx.x; i0 < nu; i0 += 4 * blockDim.x) {
+    // window w_m = h[i0 + m - j + nu - 1], m = 0..3; stepping j -> j + 1 shifts it down by one
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int idx = i0 + nu - 1;  // index of w_0 for j = 0
+    float w0 = hk[idx], w1 = hk[idx + 1], w2 = hk[idx + 2], w3 = hk[idx + 3];
+    for (int j = 0; j < nu; ++j) {
+      const float r = row[j];
+      a0 = fmaf(r, w0, a0); a1 = fmaf(r, w1, a1); a2 = fmaf(r, w2, a2); a3 = fmaf(r, w3, a3);
+      w3 = w2; w2 = w1; w1 = w0;
+      --idx;
+      w0 = (idx >= 0) ? hk[idx] : 0.f;
+    }
+    if (i0 + 0 < nu) out[base + i0 + 0] = a0 * scale;
+    if (i0 + 1 < nu) out[base + i0 + 1] = a1 * scale;
+    if (i0 + 2 < nu) out[base + i0 + 2] = a2 * scale;
+    if (i0 + 3 < nu) out[base + i0 + 3] = a3 * scale;
+  }
+}
+
+__global__ void smooth_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int nu, int nv, int n, const float* __restrict__ ky, int nk) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n * nv * nu;
+  if (i >= total) return;
+  const int iu = (int)(i % nu), iv = (int)((i / nu) % nv);
+  const size_t plane = i - (size_t)iv * nu - iu;
+  const int hk = nk / 2;
+  float acc = 0.f;
+  for (int j = 0; j < nk; ++j) {
+    int r = iv + j - hk;
+    r = r < 0 ? 0 : (r > nv - 1 ? nv - 1 : r);  // edge replicated
+    acc += ky[j] * in[plane + (size_t)r * nu + iu];
+  }
+  out[i] = acc;
+}
+
+struct BackArgs {
+  int nx, ny, nz, nu, nv, nb;  // nb = projections in this batch
+  float x0, y0, z0, sx, sy, sz;
+  float sid, sdd, inv_du, inv_dv, u0, v0, dbeta;
+  ProjParam pp[kBatch];
+};
+
+__global__ __launch_bounds__(256) void backproject_kernel(float* __restrict__ vol, const float* __restrict__ q /*[nb][nv][nu]*/, const BackArgs A) {
+  const int ix = blockIdx.x * blockDim.x + threadIdx.x, iz = blockIdx.y;
+  if (ix >= A.nx) return;
+  const float X = A.x0 + A.sx * ix, Z = A.z0 + A.sz * iz;
+  int iu[kBatch];
+  float au[kBatch], wg[kBatch], av_a[kBatch], av_b[kBatch];
+#pragma unroll
+  for (int k = 0; k < kBatch; ++k) {
+    iu[k] = -1; au[k] = 0.f; wg[k] = 0.f; av_a[k] = 0.f; av_b[k] = 0.f;
+    if (k < A.nb) {
+      const float xr = X * A.pp[k].c - Z * A.pp[k].s, zr = X * A.pp[k].s + Z * A.pp[k].c;
+      const float U = A.sid - zr, mag = A.sdd / U;
+      const float fu = (mag * xr - A.pp[k].off_x - A.u0) * A.inv_du;
+      const float fl = floorf(fu);
+      const int i = (int)fl;
+      if (i >= 0 && i < A.nu - 1) {
+        iu[k] = i;
+        au[k] = fu - fl;
+        const float r = A.sid / U;
+        wg[k] = A.dbeta * r * r;
+        av_a[k] = mag * A.inv_dv;                                  // fv = av_a * Y + av_b
+        av_b[k] = (-A.pp[k].off_y - A.v0) * A.inv_dv;
+      }
+    }
+  }
+  const size_t plane = (size_t)A.nu * A.nv;
+  float* out = vol + ((size_t)iz * A.ny) * A.nx + ix;
+  for (int iy = 0; iy < A.ny; ++iy) {
+    const float Y = A.y0 + A.sy * iy;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      if (iu[k] >= 0) {
+        const float fv = fmaf(av_a[k], Y, av_b[k]);
+        const float fl = floorf(fv);
+        const int iv = (int)fl;
+        if (iv >= 0 && iv < A.nv - 1) {
+          const float av = fv - fl;
+          const float* r0 = q + (size_t)k * plane + (size_t)iv * A.nu + iu[k];
+          const float v00 = r0[0], v01 = r0[1], v10 = r0[A.nu], v11 = r0[A.nu + 1];
+          const float top = fmaf(au[k], v01 - v00, v00), bot = fmaf(au[k], v11 - v10, v10);
+          acc = fmaf(wg[k], fmaf(av, bot - top, top), acc);
+        }
+      }
+    }
+    out[(size_t)iy * A.nx] += acc;
+  }
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------------------
+void fft(std::vector<std::complex<double>>& a, bool inverse) {  // radix 2, in place
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const double ang = 2.0 * M_PI / (double)len * (inverse ? 1.0 : -1.0);
+    const std::complex<double> wl(std::cos(ang), std::sin(ang));
+    for (size_t i = 0; i < n; i += len) {
+      std::complex<double> w(1.0, 0.0);
+      for (size_t k = 0; k < len / 2; ++k) {
+        const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+        a[i + k] = u + v;
+        a[i + k + len / 2] = u - v;
+        w *= wl;
+      }
+    }
+  }
+  if (inverse)
+    for (auto& x : a) x /= (double)n;
+}
+
+// oracle/fdk_oracle.py: ramp_kernel
+std::vector<double> ramp_kernel(int n_half, double hann) {
+  std::vector<double> h(2 * n_half + 1, 0.0);
+  for (int n = -n_half; n <= n_half; ++n) {
+    if (n == 0) h[n + n_half] = 0.25;
+    else if (n % 2 != 0) h[n + n_half] = -1.0 / (M_PI * M_PI * (double)n * (double)n);
+  }
+  if (hann > 0.0) {
+    size_t m = 1;
+    while (m < (size_t)8 * (2 * n_half + 1)) m *= 2;
+    std::vector<std::complex<double>> buf(m, 0.0);
+    for (int i = 0; i <= n_half; ++i) buf[i] = h[n_half + i];
+    for (int i = 1; i <= n_half; ++i) buf[m - i] = h[n_half - i];
+    fft(buf, false);
+    const double fc = 0.5 * hann;
+    for (size_t i = 0; i < m; ++i) {
+      const double f = (i < m / 2) ? (double)i / (double)m : (double)i / (double)m - 1.0;
+      const double win = (std::fabs(f) < fc) ? 0.5 * (1.0 + std::cos(M_PI * f / fc)) : 0.0;
+      buf[i] *= win;
+    }
+    fft(buf, true);
+    for (int i = 0; i <= n_half; ++i) h[n_half + i] = buf[i].real();
+    for (int i = 1; i <= n_half; ++i) h[n_half - i] = buf[m - i].real();
+  }
+  return h;
+}
+
+std::vector<double> hann_y_kernel(double hann_y) {
+  if (hann_y <= 0.0) return {1.0};
+  if (hann_y == 1.0) return {0.25, 0.5, 0.25};
+  const size_t m = 4096;
+  const int n_half = 8;
+  std::vector<std::complex<double>> buf(m);
+  const double fc = 0.5 * hann_y;
+  for (size_t i = 0; i < m; ++i) {
+    const double f = (i < m / 2) ? (double)i / (double)m : (double)i / (double)m - 1.0;
+    buf[i] = (std::fabs(f) < fc) ? 0.5 * (1.0 + std::cos(M_PI * f / fc)) : 0.0;
+  }
+  fft(buf, true);
+  std::vector<double> k(2 * n_half + 1);
+  for (int i = 0; i <= n_half; ++i) k[n_half + i] = buf[i].real();
+  for (int i = 1; i <= n_half; ++i) k[n_half - i] = buf[m - i].real();
+  double sum = 0.0;
+  for (double v : k) sum += v;
+  for (double& v : k) v /= sum;  // truncated support: keep the DC gain at exactly 1
+  return k;
+}
+
+// oracle/fdk_oracle.py: displaced_weights (Wang 2002) for the columns of one projection
+void displaced_weights(int nu, double du, double u0, double off_x, double sdd, float* w) {
+  const double lo = u0 + off_x, hi = u0 + du * (nu - 1) + off_x;
+  if (lo >= 0.0 || hi <= 0.0) { for (int i = 0; i < nu; ++i) w[i] = 1.f; return; }
+  const double theta = std::min(-lo, hi);
+  if (std::fabs((-lo) - hi) < 1e-9 * std::max(-lo, hi)) { for (int i = 0; i < nu; ++i) w[i] = 0.5f; return; }
+  const double sign = (hi > -lo) ? 1.0 : -1.0;
+  for (int i = 0; i < nu; ++i) {
+    const double s = sign * (u0 + du * i + off_x);
+    double v = (s > theta) ? 1.0 : 0.0;
+    if (std::fabs(s) <= theta) v = 0.5 * (std::sin(M_PI * std::atan(s / sdd) / (2.0 * std::atan(theta / sdd))) + 1.0);
+    w[i] = (float)v;
+  }
+}
+
+struct FdkError { std::string msg; };
+#define FDK_HIP(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess) throw FdkError{std::string("!!HIP ERROR!! ") + #expr + ": " + hipGetErrorString(_e)}; \
+  } while (0)
+
+}  // namespace
+
+extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* projections, float* volume, mcgpu_fdk_report* report) {
+  if (!o || !projections || !volume || o->n_proj < 1 || o->nu < 2 || o->nv < 2 || o->nx < 1 || o->ny < 1 || o->nz < 1 || !o->gantry_deg ||
+      !(o->du > 0) || !(o->dv > 0) || !(o->sid > 0) || !(o->sdd > 0)) {
+    mcgpu_set_last_error_("!!ERROR!! mcgpu_fdk_reconstruct: bad argument");
+    return -1;
+  }
+  float *d_free_raw = nullptr, *d_in = nullptr, *d_tmp = nullptr, *d_vol = nullptr, *d_h = nullptr, *d_ky = nullptr, *d_wdis = nullptr, *d_wpc = nullptr;
+  ProjParam* d_pp = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+  int rc = 0;
+  try {
+    FDK_HIP(hipSetDevice(o->device));
+    const int n = o->n_proj, nu = o->nu, nv = o->nv;
+    const size_t plane = (size_t)nu * nv, nvox = (size_t)o->nx * o->ny * o->nz;
+    const std::vector<double> kyd = hann_y_kernel(o->hann_y);
+    std::vector<float> ky(kyd.begin(), kyd.end());
+    std::vector<ProjParam> pp(n);
+    std::vector<float> wdis((size_t)n * nu);
+    for (int k = 0; k < n; ++k) {
+      const double t = o->gantry_deg[k] * M_PI / 180.0;
+      const double ox = o->proj_offset_x ? o->proj_offset_x[k] : 0.0, oy = o->proj_offset_y ? o->proj_offset_y[k] : 0.0;
+      pp[k] = {(float)std::cos(t), (float)std::sin(t), (float)ox, (float)oy};
+      displaced_weights(nu, o->du, o->u0, ox, o->sdd, &wdis[(size_t)k * nu]);
+    }
+    const double ox0 = std::isnan(o->ox) ? -(o->nx - 1) / 2.0 * o->sx : o->ox, oy0 = std::isnan(o->oy) ? -(o->ny - 1) / 2.0 * o->sy : o->oy,
+                 oz0 = std::isnan(o->oz) ? -(o->nz - 1) / 2.0 * o->sz : o->oz;
+    // symmetric padding of an off-centre detector (oracle/fdk_oracle.py: symmetric_padding)
+    int pad_l = 0, pad_r = 0;
+    {
+      double off_min = 1e300, off_max = -1e300;
+      for (int k = 0; k < n; ++k) { off_min = std::min(off_min, (double)pp[k].off_x); off_max = std::max(off_max, (double)pp[k].off_x); }
+      const double last = o->u0 + (nu - 1) * o->du;
+      const double lo = o->u0 + off_min, hi = last + off_max;
+      if (lo < 0.0 && hi > 0.0) {
+        const double extent = std::max(std::max(-(o->u0 + off_min), -(o->u0 + off_max)), std::max(last + off_min, last + off_max));
+        pad_l = std::max(0, (int)std::ceil((extent + (o->u0 + off_min)) / o->du - 1e-9));
+        pad_r = std::max(0, (int)std::ceil((extent - (last + off_max)) / o->du - 1e-9));
+      }
+    }
+    const int nu_p = nu + pad_l + pad_r;
+    const double u0_p = o->u0 - pad_l * o->du;
+    const size_t plane_p = (size_t)nu_p * nv;
+    const int chunk = std::min(n, 64);  // projections resident on the device at a time (multiple of kBatch)
+    float* d_raw = nullptr;
+    FDK_HIP(hipMalloc(&d_raw, (size_t)chunk * plane * 4));
+    d_free_raw = d_raw;
+    FDK_HIP(hipMalloc(&d_in, (size_t)chunk * plane_p * 4));
+    FDK_HIP(hipMalloc(&d_tmp, (size_t)chunk * plane_p * 4));
+    FDK_HIP(hipMalloc(&d_vol, nvox * 4));
+    FDK_HIP(hipMemset(d_vol, 0, nvox * 4));
+    const std::vector<double> hd = ramp_kernel(nu_p - 1, o->hann);
+    std::vector<float> h(hd.begin(), hd.end());
+    FDK_HIP(hipMalloc(&d_h, h.size() * 4));
+    FDK_HIP(hipMemcpy(d_h, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    FDK_HIP(hipMalloc(&d_ky, ky.size() * 4));
+    FDK_HIP(hipMemcpy(d_ky, ky.data(), ky.size() * 4, hipMemcpyHostToDevice));
+    FDK_HIP(hipMalloc(&d_wdis, wdis.size() * 4));
+    FDK_HIP(hipMemcpy(d_wdis, wdis.data(), wdis.size() * 4, hipMemcpyHostToDevice));
+    FDK_HIP(hipMalloc(&d_pp, pp.size() * sizeof(ProjParam)));
+    FDK_HIP(hipMemcpy(d_pp, pp.data(), pp.size() * sizeof(ProjParam), hipMemcpyHostToDevice));
+    std::vector<float> wpc;
+    for (int j = 0; j < o->n_wpc; ++j) wpc.push_back((float)o->wpc[j]);
+    if (!wpc.empty()) {
+      FDK_HIP(hipMalloc(&d_wpc, wpc.size() * 4));
+      FDK_HIP(hipMemcpy(d_wpc, wpc.data(), wpc.size() * 4, hipMemcpyHostToDevice));
+    }
+    FDK_HIP(hipEventCreate(&e0)); FDK_HIP(hipEventCreate(&e1)); FDK_HIP(hipEventCreate(&e2)); FDK_HIP(hipEventCreate(&e3));
+    double ms_filter = 0.0, ms_back = 0.0;
+    const size_t lds_ramp = ((size_t)nu_p + 2 * nu_p + 2) * 4;
+    if (lds_ramp > 64 * 1024)
+      FDK_HIP(hipFuncSetAttribute((const void*)ramp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ramp));
+    for (int first = 0; first < n; first += chunk) {
+      const int m = std::min(chunk, n - first);
+      const size_t elems = (size_t)m * plane_p;
+      FDK_HIP(hipMemcpy(d_raw, projections + (size_t)first * plane, (size_t)m * plane * 4, hipMemcpyHostToDevice));
+      FDK_HIP(hipEventRecord(e0, nullptr));
+      const unsigned gb = (unsigned)((elems + 255) / 256);
+      hipLaunchKernelGGL(weight_kernel, dim3(gb), dim3(256), 0, nullptr, d_raw, d_in, nu, nv, m, nu_p, pad_l, (float)o->du, (float)o->dv, (float)o->u0,
+                         (float)o->v0, (float)o->sdd, d_pp + first, d_wdis + (size_t)first * nu, d_wpc, (int)wpc.size());
+      hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_p, (float)((o->sdd / o->sid) / o->du));
+      const float* filtered = d_tmp;
+      if (ky.size() > 1) {
+        hipLaunchKernelGGL(smooth_cols_kernel, dim3(gb), dim3(256), 0, nullptr, d_tmp, d_in, nu_p, nv, m, d_ky, (int)ky.size());
+        filtered = d_in;
+      }
+      FDK_HIP(hipEventRecord(e1, nullptr));
+      for (int b = 0; b < m; b += kBatch) {
+        BackArgs A;
+        A.nx = o->nx; A.ny = o->ny; A.nz = o->nz; A.nu = nu_p; A.nv = nv; A.nb = std::min(kBatch, m - b);
+        A.x0 = (float)ox0; A.y0 = (float)oy0; A.z0 = (float)oz0; A.sx = (float)o->sx; A.sy = (float)o->sy; A.sz = (float)o->sz;
+        A.sid = (float)o->sid; A.sdd = (float)o->sdd; A.inv_du = (float)(1.0 / o->du); A.inv_dv = (float)(1.0 / o->dv);
+        A.u0 = (float)u0_p; A.v0 = (float)o->v0; A.dbeta = (float)(2.0 * M_PI / n);
+        for (int k = 0; k < kBatch; ++k) A.pp[k] = (k < A.nb) ? pp[first + b + k] : ProjParam{1.f, 0.f, 0.f, 0.f};
+        hipLaunchKernelGGL(backproject_kernel, dim3((unsigned)((o->nx + 255) / 256), (unsigned)o->nz), dim3(256), 0, nullptr, d_vol,
+                           filtered + (size_t)b * plane_p, A);
+      }
+      FDK_HIP(hipEventRecord(e2, nullptr));
+      FDK_HIP(hipEventSynchronize(e2));
+      float a = 0.f, bms = 0.f;
+      FDK_HIP(hipEventElapsedTime(&a, e0, e1));
+      FDK_HIP(hipEventElapsedTime(&bms, e1, e2));
+      ms_filter += a; ms_back += bms;
+    }
+    FDK_HIP(hipGetLastError());
+    FDK_HIP(hipMemcpy(volume, d_vol, nvox * 4, hipMemcpyDeviceToHost));
+    if (report) { report->ms_filter = ms_filter; report->ms_backproject = ms_back; }
+  } catch (const FdkError& e) {
+    mcgpu_set_last_error_(e.msg.c_str());
+    rc = -1;
+  }
+  for (void* p : {(void*)d_free_raw, (void*)d_in, (void*)d_tmp, (void*)d_vol, (void*)d_h, (void*)d_ky, (void*)d_wdis, (void*)d_wpc, (void*)d_pp})
+    if (p) (void)hipFree(p);
+  for (hipEvent_t e : {e0, e1, e2, e3})
+    if (e) (void)hipEventDestroy(e);
+  return rc;
+}

@@ -1,0 +1,200 @@
+"""FDK reconstruction of projection stacks on the MI355X -- the in-process stand-in for the reference's `rtkfdk` call
+(cbctmc/reconstruction/reconstruction.py:22-69 `reconstruct_3d`, reconstructors.py `FDKReconstructor`).
+
+`reconstruct_3d` keeps the reference's signature and file contract: a normalised projection stack (`.mha`, line
+integrals), an RTK circular-geometry XML file, `dimension` / `spacing` / `pad` / `hann` / `hann_y` /
+`water_pre_correction`, output `recon_fdk3d.mha` + a `.yaml` with the parameters.  `create_geometry` mirrors
+cbctmc/forward_projection.py:152-199 without the `itk-rtk` wheel and writes the XML RTK's geometry reader understands.
+The arithmetic is `csrc/fdk.hip` through `mcgpu_fdk_reconstruct`; there is no CPU fallback.  Parity against RTK itself is
+unpinned (RTK is not available to this repository); the oracle and its analytic pins are in oracle/fdk_oracle.py."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import defaults
+
+
+@dataclass
+class CircularGeometry:
+    """Subset of rtk::ThreeDCircularProjectionGeometry the reference uses (AddProjection(sid, sdd, angle, offx, offy))."""
+    source_to_isocenter: float
+    source_to_detector: float
+    gantry_angles: List[float] = field(default_factory=list)       # degrees
+    projection_offsets_x: List[float] = field(default_factory=list)  # mm
+    projection_offsets_y: List[float] = field(default_factory=list)
+
+    def add_projection(self, angle: float, offset_x: float = 0.0, offset_y: float = 0.0):
+        self.gantry_angles.append(float(angle) % 360.0)
+        self.projection_offsets_x.append(float(offset_x))
+        self.projection_offsets_y.append(float(offset_y))
+
+    def matrix(self, i: int) -> np.ndarray:
+        """3x4 projection matrix of projection i (RTK: translation * magnification * rotation, zero source offsets)."""
+        t = np.deg2rad(self.gantry_angles[i])
+        c, s = np.cos(t), np.sin(t)
+        sid, sdd = self.source_to_isocenter, self.source_to_detector
+        rot = np.array([[c, 0.0, -s, 0.0], [0.0, 1.0, 0.0, 0.0], [s, 0.0, c, 0.0], [0.0, 0.0, 0.0, 1.0]])
+        mag = np.array([[-sdd, 0.0, 0.0, 0.0], [0.0, -sdd, 0.0, 0.0], [0.0, 0.0, 1.0, -sid]])
+        tra = np.array([[1.0, 0.0, -self.projection_offsets_x[i]], [0.0, 1.0, -self.projection_offsets_y[i]], [0.0, 0.0, 1.0]])
+        return tra @ mag @ rot
+
+    def write(self, path) -> Path:
+        path = Path(path)
+        L = ['<?xml version="1.0"?>', "<!DOCTYPE RTKGEOMETRY>", '<RTKThreeDCircularGeometry version="3">',
+             f"  <SourceToIsocenterDistance>{self.source_to_isocenter:.17g}</SourceToIsocenterDistance>",
+             f"  <SourceToDetectorDistance>{self.source_to_detector:.17g}</SourceToDetectorDistance>"]
+        for i, a in enumerate(self.gantry_angles):
+            L.append("  <Projection>")
+            L.append(f"    <GantryAngle>{a:.17g}</GantryAngle>")
+            L.append(f"    <ProjectionOffsetX>{self.projection_offsets_x[i]:.17g}</ProjectionOffsetX>")
+            L.append(f"    <ProjectionOffsetY>{self.projection_offsets_y[i]:.17g}</ProjectionOffsetY>")
+            m = self.matrix(i)
+            L.append("    <Matrix>")
+            for row in m:
+                L.append("      " + " ".join(f"{v:.15g}" for v in row))
+            L.append("    </Matrix>")
+            L.append("  </Projection>")
+        L.append("</RTKThreeDCircularGeometry>")
+        path.write_text("\n".join(L) + "\n")
+        return path
+
+    @classmethod
+    def read(cls, path) -> "CircularGeometry":
+        text = Path(path).read_text()
+
+        def tag(name, s, default=None):
+            m = re.search(rf"<{name}>\s*([^<]+?)\s*</{name}>", s)
+            return float(m.group(1)) if m else default
+
+        head = text.split("<Projection>")[0]
+        sid, sdd = tag("SourceToIsocenterDistance", head), tag("SourceToDetectorDistance", head)
+        if sid is None or sdd is None:
+            raise ValueError(f"{path}: not an RTK circular geometry file")
+        g = cls(sid, sdd)
+        gx, gy = tag("ProjectionOffsetX", head, 0.0), tag("ProjectionOffsetY", head, 0.0)  # RTK hoists values shared by all projections
+        ga = tag("GantryAngle", head, 0.0)
+        for block in text.split("<Projection>")[1:]:
+            block = block.split("</Projection>")[0]
+            g.add_projection(tag("GantryAngle", block, ga), tag("ProjectionOffsetX", block, gx), tag("ProjectionOffsetY", block, gy))
+        return g
+
+
+def create_geometry(n_projections: int, start_angle: float = 270.0,
+                    source_to_isocenter: float = defaults.MCDefaults.source_to_isocenter_distance,
+                    source_to_detector: float = defaults.MCDefaults.source_to_detector_distance,
+                    detector_offset_x: float = defaults.MCDefaults.detector_lateral_displacement,
+                    detector_offset_y: float = 0.0, arc: float = 360.0) -> CircularGeometry:
+    """cbctmc/forward_projection.py:152-199 (same arguments and defaults)."""
+    g = CircularGeometry(source_to_isocenter, source_to_detector)
+    for i in range(n_projections):
+        g.add_projection(start_angle + i * arc / n_projections, detector_offset_x, detector_offset_y)
+    return g
+
+
+class _FdkOptions(C.Structure):
+    _fields_ = [("n_proj", C.c_int), ("nu", C.c_int), ("nv", C.c_int), ("du", C.c_double), ("dv", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
+                ("sid", C.c_double), ("sdd", C.c_double), ("gantry_deg", C.POINTER(C.c_double)), ("proj_offset_x", C.POINTER(C.c_double)),
+                ("proj_offset_y", C.POINTER(C.c_double)), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("sx", C.c_double), ("sy", C.c_double),
+                ("sz", C.c_double), ("ox", C.c_double), ("oy", C.c_double), ("oz", C.c_double), ("hann", C.c_double), ("hann_y", C.c_double),
+                ("wpc", C.POINTER(C.c_double)), ("n_wpc", C.c_int), ("device", C.c_int)]
+
+
+class _FdkReport(C.Structure):
+    _fields_ = [("ms_filter", C.c_double), ("ms_backproject", C.c_double)]
+
+
+def fdk(projections: np.ndarray, geometry: CircularGeometry, pixel_spacing: Tuple[float, float], pixel_origin: Optional[Tuple[float, float]] = None,
+        dimension: Tuple[int, int, int] = (464, 250, 464), spacing: Tuple[float, float, float] = (1.0, 1.0, 1.0),
+        origin: Optional[Tuple[float, float, float]] = None, hann: float = 0.0, hann_y: float = 0.0,
+        water_pre_correction: Optional[Sequence[float]] = None, gpu_id: int = 0):
+    """projections [n, nv, nu] (line integrals) -> (volume [nz, ny, nx] float32 in RTK's IEC frame, report dict)."""
+    from . import engine
+    lib = engine.load_library()
+    lib.mcgpu_fdk_reconstruct.argtypes = [C.POINTER(_FdkOptions), C.c_void_p, C.c_void_p, C.POINTER(_FdkReport)]
+    lib.mcgpu_fdk_reconstruct.restype = C.c_int
+    p = np.ascontiguousarray(projections, dtype=np.float32)
+    n, nv, nu = p.shape
+    if n != len(geometry.gantry_angles):
+        raise ValueError(f"{n} projections but {len(geometry.gantry_angles)} geometry entries")
+    du, dv = float(pixel_spacing[0]), float(pixel_spacing[1])
+    u0, v0 = pixel_origin if pixel_origin is not None else (-(nu - 1) / 2 * du, -(nv - 1) / 2 * dv)
+    ang = np.ascontiguousarray(geometry.gantry_angles, dtype=np.float64)
+    ox = np.ascontiguousarray(geometry.projection_offsets_x, dtype=np.float64)
+    oy = np.ascontiguousarray(geometry.projection_offsets_y, dtype=np.float64)
+    wpc = np.ascontiguousarray(water_pre_correction if water_pre_correction is not None else [], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    o = _FdkOptions(n, nu, nv, du, dv, float(u0), float(v0), float(geometry.source_to_isocenter), float(geometry.source_to_detector),
+                    ang.ctypes.data_as(dp), ox.ctypes.data_as(dp), oy.ctypes.data_as(dp), int(dimension[0]), int(dimension[1]), int(dimension[2]),
+                    float(spacing[0]), float(spacing[1]), float(spacing[2]),
+                    *(tuple(float(v) for v in origin) if origin is not None else (float("nan"),) * 3), float(hann), float(hann_y),
+                    wpc.ctypes.data_as(dp) if wpc.size else None, int(wpc.size), int(gpu_id))
+    vol = np.zeros((int(dimension[2]), int(dimension[1]), int(dimension[0])), dtype=np.float32)
+    rep = _FdkReport()
+    engine._check(lib.mcgpu_fdk_reconstruct(C.byref(o), p.ctypes.data, vol.ctypes.data, C.byref(rep)))
+    return vol, {"ms_filter": rep.ms_filter, "ms_backproject": rep.ms_backproject}
+
+
+def read_mha(path):
+    """(array [n2, n1, n0] float32, spacing, origin) of an uncompressed MetaImage written by this engine or SimpleITK."""
+    raw = Path(path).read_bytes()
+    head_end = raw.index(b"ElementDataFile")
+    head_end = raw.index(b"\n", head_end) + 1
+    meta = {}
+    for line in raw[:head_end].decode("latin-1").splitlines():
+        if "=" in line:
+            k, v = line.split("=", 1)
+            meta[k.strip()] = v.strip()
+    if meta.get("ElementDataFile") != "LOCAL" or meta.get("ElementType") != "MET_FLOAT" or meta.get("CompressedData", "False") == "True":
+        raise ValueError(f"{path}: only uncompressed MET_FLOAT MetaImages with local data are supported")
+    dims = [int(v) for v in meta["DimSize"].split()]
+    spacing = [float(v) for v in meta.get("ElementSpacing", "1 1 1").split()]
+    origin = [float(v) for v in meta.get("Offset", meta.get("Origin", "0 0 0")).split()]
+    data = np.frombuffer(raw, dtype="<f4", offset=head_end, count=int(np.prod(dims))).reshape(dims[::-1])
+    return data, spacing, origin
+
+
+def write_mha(path, volume: np.ndarray, spacing, origin) -> Path:
+    """float32 [n2, n1, n0] -> uncompressed MetaImage (what SimpleITK.WriteImage produces for such an image)."""
+    path = Path(path)
+    v = np.ascontiguousarray(volume, dtype="<f4")
+    d = v.shape[::-1]
+    head = ("ObjectType = Image\nNDims = 3\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\n"
+            "TransformMatrix = 1 0 0 0 1 0 0 0 1\n"
+            f"Offset = {origin[0]:.15g} {origin[1]:.15g} {origin[2]:.15g}\nCenterOfRotation = 0 0 0\nAnatomicalOrientation = RAI\n"
+            f"ElementSpacing = {spacing[0]:.15g} {spacing[1]:.15g} {spacing[2]:.15g}\nDimSize = {d[0]} {d[1]} {d[2]}\n"
+            "ElementType = MET_FLOAT\nElementDataFile = LOCAL\n")
+    with open(path, "wb") as f:
+        f.write(head.encode())
+        f.write(v.tobytes())
+    return path
+
+
+def reconstruct_3d(projections_filepath, geometry_filepath, output_folder=None, output_filename: Optional[str] = None,
+                   dimension: Tuple[int, int, int] = (464, 250, 464), spacing: Tuple[float, float, float] = (1.0, 1.0, 1.0), pad: float = 1.0,
+                   hann: float = 1.0, hann_y: float = 1.0, water_pre_correction: Optional[Sequence[float]] = None, gpu_id: int = 0, **kwargs):
+    """cbctmc/reconstruction/reconstruction.py:22-69 with `rtkfdk --hardware cuda` replaced by the in-process kernels.
+    `pad` is accepted for compatibility: rows are zero-padded for the linear convolution, there is no edge extrapolation."""
+    projections_filepath, geometry_filepath = Path(projections_filepath), Path(geometry_filepath)
+    output_folder = Path(output_folder) if output_folder else projections_filepath.parent / "reconstructions"
+    output_filename = output_filename or "recon_fdk3d.mha"
+    output_folder.mkdir(parents=True, exist_ok=True)
+    proj, pspacing, porigin = read_mha(projections_filepath)
+    geometry = CircularGeometry.read(geometry_filepath)
+    vol, report = fdk(proj, geometry, (pspacing[0], pspacing[1]), (porigin[0], porigin[1]), dimension, spacing, None, hann, hann_y,
+                      water_pre_correction, gpu_id)
+    origin = tuple(-(n - 1) / 2 * s for n, s in zip(dimension, spacing))
+    write_mha(output_folder / output_filename, vol, spacing, origin)
+    import yaml
+    params = dict(path=str(projections_filepath.parent), regexp=projections_filepath.name, geometry=str(geometry_filepath), hardware="hip", pad=pad,
+                  hann=hann, hannY=hann_y, dimension=list(dimension), spacing=list(spacing),
+                  wpc=list(water_pre_correction) if water_pre_correction is not None else None, short=360,
+                  output_filepath=str(output_folder / output_filename), **kwargs)
+    with open((output_folder / output_filename).with_suffix(".yaml"), "w") as f:
+        yaml.dump(params, f)
+    return output_folder / output_filename, report

@@ -210,6 +210,34 @@ int mcgpu_write_voxel_binary(const char *path, const int n[3], const float spaci
 int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n, float *out_f32);
 int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, double *out_exp, double *out_sin, double *out_cos);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row f4: FDK reconstruction of a projection stack (what the reference obtains from `rtkfdk --hardware cuda`,
+ * cbctmc/reconstruction/reconstruction.py:22-69).  RTK geometry conventions (rotation axis y, source at
+ * Ry(gantry) (0,0,sid), detector coordinate u = sdd x'/(sid - z') - proj_offset_x); projections are line integrals
+ * [n_proj][nv][nu] on the host, pixel (i, j) centred at (u0 + i du, v0 + j dv); the volume is written [nz][ny][nx],
+ * voxel (0,0,0) centred at (ox, oy, oz) (NaN = volume centred on the isocentre).  hann / hann_y: cut-off of the Hann
+ * windows as fractions of Nyquist (0 = plain ramp / no vertical smoothing); wpc: optional water pre-correction
+ * polynomial coefficients (rtkfdk --wpc).  Displaced (half-fan) detectors are weighted automatically. */
+typedef struct mcgpu_fdk_options {
+  int n_proj, nu, nv;
+  double du, dv, u0, v0;
+  double sid, sdd;
+  const double *gantry_deg;     /* [n_proj] */
+  const double *proj_offset_x;  /* [n_proj] or NULL (0) */
+  const double *proj_offset_y;  /* [n_proj] or NULL (0) */
+  int nx, ny, nz;
+  double sx, sy, sz, ox, oy, oz;
+  double hann, hann_y;
+  const double *wpc;
+  int n_wpc;
+  int device;
+} mcgpu_fdk_options;
+typedef struct mcgpu_fdk_report {
+  double ms_filter;      /* weight + ramp + vertical smoothing kernels */
+  double ms_backproject; /* back-projection kernels */
+} mcgpu_fdk_report;
+int mcgpu_fdk_reconstruct(const mcgpu_fdk_options *options, const float *projections, float *volume, mcgpu_fdk_report *report);
+
 #ifdef __cplusplus
 }
 #endif
