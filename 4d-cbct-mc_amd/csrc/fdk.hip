@@ -8,13 +8,16 @@
 //                 four outputs per thread from a sliding register window: 0.5 LDS reads per FMA                 (LDS/VALU)
 //   smooth_cols : --hannY low-pass along v (3 taps for 1.0)                                                     (streaming)
 //   backproject : voxel-driven, bilinear; a thread owns one (x, z) column of the volume, precomputes everything that does
-//                 not depend on y for a batch of 16 projections in registers, then walks y: 4 loads + 10 flops per update;
-//                 the filtered projections of a batch (3 MB each) stay L2-resident                              (L2 gather)
+//                 not depend on y for a batch of 8 projections in registers, then walks y: 4 loads + 10 flops per update;
+//                 the filtered projections of a batch (5.7 MB each, padded) stay L2 / Infinity-Cache resident.  One voxel step
+//                 is 3.9 detector pixels, so the 4 loads of a wave touch ~32 cache lines for 64 updates: the vector L1
+//                 (64 B/clk/CU) bounds the kernel at ~1 update/clk/CU; measured 0.78                              (L1/L2 gather)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,7 +28,9 @@ extern "C" void mcgpu_set_last_error_(const char* message);
 
 namespace {
 
-constexpr int kBatch = 16;  // projections per back-projection launch
+// projections per back-projection launch.  Measured at the reference's size (tools/fdk_bench.py): 8 projections and 4 waves per
+// SIMD (78 VGPRs) 101 ms; 16 / 4 waves (128 VGPRs + scratch) 133 ms; 8 / 8 waves (scratch) 132 ms; 32 / 2 waves 215 ms
+constexpr int kBatch = 8;
 
 struct ProjParam {  // per projection, wave-uniform in the kernels
   float c, s;       // cos / sin of the gantry angle
@@ -57,7 +62,8 @@ __global__ void weight_kernel(const float* __restrict__ in, float* __restrict__ 
 }
 
 // out[row][i] = scale * sum_j in[row][j] * h[i - j + nu - 1];  one block per row, 256 threads, 4 consecutive outputs per thread
-__global__ __launch_bounds__(256) void ramp_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ h, int nu, float scale) {
+__global__ __launch_bounds__(256) void ramp_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ h, int nu, float scale,
+                                                        int j0, int j1 /* columns outside [j0, j1) are zero (padding) */) {
   extern __shared__ float lds[];
   float* row = lds;             // [nu]
   float* hk = lds + nu;         // [2 nu - 1 + 3] (padded with zeros so that the window may run past the ends)
@@ -68,9 +74,9 @@ __global__ __launch_bounds__(256) void ramp_rows_kernel(const float* __restrict_
   for (int i0 = 4 * threadIdx.x; i0 < nu; i0 += 4 * blockDim.x) {
     // window w_m = h[i0 + m - j + nu - 1], m = 0..3; stepping j -> j + 1 shifts it down by one
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int idx = i0 + nu - 1;  // index of w_0 for j = 0
+    int idx = i0 + nu - 1 - j0;  // index of w_0 for j = j0
     float w0 = hk[idx], w1 = hk[idx + 1], w2 = hk[idx + 2], w3 = hk[idx + 3];
-    for (int j = 0; j < nu; ++j) {
+    for (int j = j0; j < j1; ++j) {
       const float r = row[j];
       a0 = fmaf(r, w0, a0); a1 = fmaf(r, w1, a1); a2 = fmaf(r, w2, a2); a3 = fmaf(r, w3, a3);
       w3 = w2; w2 = w1; w1 = w0;
@@ -107,7 +113,7 @@ struct BackArgs {
   ProjParam pp[kBatch];
 };
 
-__global__ __launch_bounds__(256) void backproject_kernel(float* __restrict__ vol, const float* __restrict__ q /*[nb][nv][nu]*/, const BackArgs A) {
+__global__ __launch_bounds__(256, 4) void backproject_kernel(float* __restrict__ vol, const float* __restrict__ q /*[nb][nv][nu]*/, const BackArgs A) {
   const int ix = blockIdx.x * blockDim.x + threadIdx.x, iz = blockIdx.y;
   if (ix >= A.nx) return;
   const float X = A.x0 + A.sx * ix, Z = A.z0 + A.sz * iz;
@@ -333,7 +339,8 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
       const unsigned gb = (unsigned)((elems + 255) / 256);
       hipLaunchKernelGGL(weight_kernel, dim3(gb), dim3(256), 0, nullptr, d_raw, d_in, nu, nv, m, nu_p, pad_l, (float)o->du, (float)o->dv, (float)o->u0,
                          (float)o->v0, (float)o->sdd, d_pp + first, d_wdis + (size_t)first * nu, d_wpc, (int)wpc.size());
-      hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_p, (float)((o->sdd / o->sid) / o->du));
+      hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_p, (float)((o->sdd / o->sid) / o->du),
+                         pad_l, pad_l + nu);
       const float* filtered = d_tmp;
       if (ky.size() > 1) {
         hipLaunchKernelGGL(smooth_cols_kernel, dim3(gb), dim3(256), 0, nullptr, d_tmp, d_in, nu_p, nv, m, d_ky, (int)ky.size());
