@@ -4,8 +4,8 @@
 // (parity unpinned against RTK, pinned by analytic phantoms) and implemented here as four kernels:
 //   weight      : water pre-correction polynomial, cosine weight, displaced-detector (half-fan) weight, zero padding of the
 //                 short side to a detector symmetric about the central ray                                     (streaming)
-//   ramp_rows   : linear convolution of every detector row with the (Hann-apodised) ramp kernel, row and kernel in LDS,
-//                 four outputs per thread from a sliding register window: 0.5 LDS reads per FMA                 (LDS/VALU)
+//   ramp        : rows zero-extended to L = 4096, batched hipFFT R2C -> multiply by the real spectrum of the (Hann-apodised)
+//                 ramp -> C2R (HBM streaming); ramp_rows = the direct LDS convolution kept for A/B (MCGPU_FDK_DIRECT_RAMP)
 //   smooth_cols : --hannY low-pass along v (3 taps for 1.0)                                                     (streaming)
 //   backproject : voxel-driven, bilinear; a thread owns one (x, z) column of the volume, precomputes everything that does
 //                 not depend on y for a batch of 8 projections in registers, then walks y: 4 loads + 10 flops per update;
@@ -13,6 +13,7 @@
 //                 is 3.9 detector pixels, so the 4 loads of a wave touch ~32 cache lines for 64 updates: the vector L1
 //                 (64 B/clk/CU) bounds the kernel at ~1 update/clk/CU; measured 0.78                              (L1/L2 gather)
 #include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
 
 #include <algorithm>
 #include <cmath>
@@ -39,7 +40,7 @@ struct ProjParam {  // per projection, wave-uniform in the kernels
 
 // in: [n][nv][nu] raw line integrals; out: [n][nv][nu_p] weighted rows, padded with pad_l zero columns on the left (and zeros on the
 // right) so that an off-centre detector becomes symmetric about the central ray (RTK: DisplacedDetectorImageFilter)
-__global__ void weight_kernel(const float* __restrict__ in, float* __restrict__ out, int nu, int nv, int n, int nu_p, int pad_l, float du, float dv,
+__global__ void weight_kernel(const float* __restrict__ in, float* __restrict__ out, int nu, int nv, int n, int nu_p /* row stride of out */, int pad_l, float du, float dv,
                               float u0, float v0, float sdd, const ProjParam* __restrict__ pp, const float* __restrict__ w_dis /*[n][nu]*/,
                               const float* __restrict__ wpc, int n_wpc) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,24 +91,36 @@ __global__ __launch_bounds__(256) void ramp_rows_kernel(const float* __restrict_
   }
 }
 
-__global__ void smooth_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int nu, int nv, int n, const float* __restrict__ ky, int nk) {
+// in/out rows have `stride` floats, of which the first `nu` are used
+__global__ void smooth_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int nu, int stride, int nv, int n, const float* __restrict__ ky, int nk) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n * nv * nu;
   if (i >= total) return;
-  const int iu = (int)(i % nu), iv = (int)((i / nu) % nv);
-  const size_t plane = i - (size_t)iv * nu - iu;
+  const int iu = (int)(i % nu), iv = (int)((i / nu) % nv), k = (int)(i / ((size_t)nu * nv));
+  const size_t plane = (size_t)k * nv * stride;
   const int hk = nk / 2;
   float acc = 0.f;
   for (int j = 0; j < nk; ++j) {
     int r = iv + j - hk;
     r = r < 0 ? 0 : (r > nv - 1 ? nv - 1 : r);  // edge replicated
-    acc += ky[j] * in[plane + (size_t)r * nu + iu];
+    acc += ky[j] * in[plane + (size_t)r * stride + iu];
   }
-  out[i] = acc;
+  out[plane + (size_t)iv * stride + iu] = acc;
+}
+
+// spectrum[row][k] *= H[k] (real: the ramp kernel is even), k = 0 .. L/2
+__global__ void spectrum_kernel(float2* __restrict__ spec, const float* __restrict__ H, int nk, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float h = H[i % nk];
+  float2 v = spec[i];
+  v.x *= h; v.y *= h;
+  spec[i] = v;
 }
 
 struct BackArgs {
-  int nx, ny, nz, nu, nv, nb;  // nb = projections in this batch
+  int nx, ny, nz, nu, nv, nb;  // nb = projections in this batch; nu = usable columns
+  int stride;                  // floats per detector row in q
   float x0, y0, z0, sx, sy, sz;
   float sid, sdd, inv_du, inv_dv, u0, v0, dbeta;
   ProjParam pp[kBatch];
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(256, 4) void backproject_kernel(float* __restrict__
       }
     }
   }
-  const size_t plane = (size_t)A.nu * A.nv;
+  const size_t plane = (size_t)A.stride * A.nv;
   float* out = vol + ((size_t)iz * A.ny) * A.nx + ix;
   for (int iy = 0; iy < A.ny; ++iy) {
     const float Y = A.y0 + A.sy * iy;
@@ -151,8 +164,8 @@ __global__ __launch_bounds__(256, 4) void backproject_kernel(float* __restrict__
         const int iv = (int)fl;
         if (iv >= 0 && iv < A.nv - 1) {
           const float av = fv - fl;
-          const float* r0 = q + (size_t)k * plane + (size_t)iv * A.nu + iu[k];
-          const float v00 = r0[0], v01 = r0[1], v10 = r0[A.nu], v11 = r0[A.nu + 1];
+          const float* r0 = q + (size_t)k * plane + (size_t)iv * A.stride + iu[k];
+          const float v00 = r0[0], v01 = r0[1], v10 = r0[A.stride], v11 = r0[A.stride + 1];
           const float top = fmaf(au[k], v01 - v00, v00), bot = fmaf(au[k], v11 - v10, v10);
           acc = fmaf(wg[k], fmaf(av, bot - top, top), acc);
         }
@@ -266,6 +279,8 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     mcgpu_set_last_error_("!!ERROR!! mcgpu_fdk_reconstruct: bad argument");
     return -1;
   }
+  float2* d_spec = nullptr;
+  hipfftHandle plan_fwd = 0, plan_inv = 0;
   float *d_free_raw = nullptr, *d_in = nullptr, *d_tmp = nullptr, *d_vol = nullptr, *d_h = nullptr, *d_ky = nullptr, *d_wdis = nullptr, *d_wpc = nullptr;
   ProjParam* d_pp = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
@@ -301,8 +316,15 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     }
     const int nu_p = nu + pad_l + pad_r;
     const double u0_p = o->u0 - pad_l * o->du;
-    const size_t plane_p = (size_t)nu_p * nv;
-    const int chunk = std::min(n, 64);  // projections resident on the device at a time (multiple of kBatch)
+    // Ramp filter: FFT (hipFFT, rows zero-extended to L >= 2 nu_p - 1: no wrap-around inside the nu_p columns that are used) or,
+    // with MCGPU_FDK_DIRECT_RAMP, the direct LDS convolution (same result up to float rounding; tests compare both to the oracle)
+    const bool direct = getenv("MCGPU_FDK_DIRECT_RAMP") != nullptr;
+    int L = 1;
+    while (L < 2 * nu_p - 1) L *= 2;
+    const int stride = direct ? nu_p : L;        // floats per detector row in the filtered buffers
+    const int nk = L / 2 + 1;
+    const size_t plane_p = (size_t)stride * nv;
+    const int chunk = std::min(n, direct ? 64 : 32);  // projections resident on the device at a time (multiple of kBatch)
     float* d_raw = nullptr;
     FDK_HIP(hipMalloc(&d_raw, (size_t)chunk * plane * 4));
     d_free_raw = d_raw;
@@ -311,9 +333,23 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     FDK_HIP(hipMalloc(&d_vol, nvox * 4));
     FDK_HIP(hipMemset(d_vol, 0, nvox * 4));
     const std::vector<double> hd = ramp_kernel(nu_p - 1, o->hann);
-    std::vector<float> h(hd.begin(), hd.end());
-    FDK_HIP(hipMalloc(&d_h, h.size() * 4));
-    FDK_HIP(hipMemcpy(d_h, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    const double scale = (o->sdd / o->sid) / o->du;
+    if (direct) {
+      std::vector<float> h(hd.begin(), hd.end());
+      FDK_HIP(hipMalloc(&d_h, h.size() * 4));
+      FDK_HIP(hipMemcpy(d_h, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    } else {
+      // spectrum of the kernel laid out circularly (lag n at index n mod L); real because the kernel is even;
+      // the scale of the filter and hipFFT's missing 1/L are folded in
+      std::vector<std::complex<double>> c((size_t)L, 0.0);
+      for (int lag = -(nu_p - 1); lag <= nu_p - 1; ++lag) c[(size_t)((lag + L) % L)] = hd[(size_t)(lag + nu_p - 1)];
+      fft(c, false);
+      std::vector<float> H((size_t)nk);
+      for (int k = 0; k < nk; ++k) H[(size_t)k] = (float)(c[(size_t)k].real() * scale / (double)L);
+      FDK_HIP(hipMalloc(&d_h, H.size() * 4));
+      FDK_HIP(hipMemcpy(d_h, H.data(), H.size() * 4, hipMemcpyHostToDevice));
+      FDK_HIP(hipMalloc(&d_spec, (size_t)chunk * nv * nk * sizeof(float2)));
+    }
     FDK_HIP(hipMalloc(&d_ky, ky.size() * 4));
     FDK_HIP(hipMemcpy(d_ky, ky.data(), ky.size() * 4, hipMemcpyHostToDevice));
     FDK_HIP(hipMalloc(&d_wdis, wdis.size() * 4));
@@ -329,27 +365,43 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     FDK_HIP(hipEventCreate(&e0)); FDK_HIP(hipEventCreate(&e1)); FDK_HIP(hipEventCreate(&e2)); FDK_HIP(hipEventCreate(&e3));
     double ms_filter = 0.0, ms_back = 0.0;
     const size_t lds_ramp = ((size_t)nu_p + 2 * nu_p + 2) * 4;
-    if (lds_ramp > 64 * 1024)
+    if (direct && lds_ramp > 64 * 1024)
       FDK_HIP(hipFuncSetAttribute((const void*)ramp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ramp));
+    int planned_rows = 0;
     for (int first = 0; first < n; first += chunk) {
       const int m = std::min(chunk, n - first);
       const size_t elems = (size_t)m * plane_p;
       FDK_HIP(hipMemcpy(d_raw, projections + (size_t)first * plane, (size_t)m * plane * 4, hipMemcpyHostToDevice));
+      if (!direct && planned_rows != m * nv) {  // one batched plan per chunk size (at most two: full chunks and the last one)
+        if (plan_fwd) { hipfftDestroy(plan_fwd); hipfftDestroy(plan_inv); plan_fwd = plan_inv = 0; }
+        int len[1] = {L};
+        if (hipfftPlanMany(&plan_fwd, 1, len, nullptr, 1, L, nullptr, 1, nk, HIPFFT_R2C, m * nv) != HIPFFT_SUCCESS ||
+            hipfftPlanMany(&plan_inv, 1, len, nullptr, 1, nk, nullptr, 1, L, HIPFFT_C2R, m * nv) != HIPFFT_SUCCESS)
+          throw FdkError{"!!ERROR!! mcgpu_fdk_reconstruct: hipfftPlanMany failed"};
+        planned_rows = m * nv;
+      }
       FDK_HIP(hipEventRecord(e0, nullptr));
       const unsigned gb = (unsigned)((elems + 255) / 256);
-      hipLaunchKernelGGL(weight_kernel, dim3(gb), dim3(256), 0, nullptr, d_raw, d_in, nu, nv, m, nu_p, pad_l, (float)o->du, (float)o->dv, (float)o->u0,
+      hipLaunchKernelGGL(weight_kernel, dim3(gb), dim3(256), 0, nullptr, d_raw, d_in, nu, nv, m, stride, pad_l, (float)o->du, (float)o->dv, (float)o->u0,
                          (float)o->v0, (float)o->sdd, d_pp + first, d_wdis + (size_t)first * nu, d_wpc, (int)wpc.size());
-      hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_p, (float)((o->sdd / o->sid) / o->du),
-                         pad_l, pad_l + nu);
+      if (direct) {
+        hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_p, (float)scale, pad_l, pad_l + nu);
+      } else {
+        if (hipfftExecR2C(plan_fwd, d_in, (hipfftComplex*)d_spec) != HIPFFT_SUCCESS) throw FdkError{"!!ERROR!! mcgpu_fdk_reconstruct: hipfftExecR2C failed"};
+        const size_t ns = (size_t)m * nv * nk;
+        hipLaunchKernelGGL(spectrum_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, d_spec, d_h, nk, ns);
+        if (hipfftExecC2R(plan_inv, (hipfftComplex*)d_spec, d_tmp) != HIPFFT_SUCCESS) throw FdkError{"!!ERROR!! mcgpu_fdk_reconstruct: hipfftExecC2R failed"};
+      }
       const float* filtered = d_tmp;
       if (ky.size() > 1) {
-        hipLaunchKernelGGL(smooth_cols_kernel, dim3(gb), dim3(256), 0, nullptr, d_tmp, d_in, nu_p, nv, m, d_ky, (int)ky.size());
+        const size_t na = (size_t)m * nv * nu_p;
+        hipLaunchKernelGGL(smooth_cols_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, nullptr, d_tmp, d_in, nu_p, stride, nv, m, d_ky, (int)ky.size());
         filtered = d_in;
       }
       FDK_HIP(hipEventRecord(e1, nullptr));
       for (int b = 0; b < m; b += kBatch) {
         BackArgs A;
-        A.nx = o->nx; A.ny = o->ny; A.nz = o->nz; A.nu = nu_p; A.nv = nv; A.nb = std::min(kBatch, m - b);
+        A.nx = o->nx; A.ny = o->ny; A.nz = o->nz; A.nu = nu_p; A.stride = stride; A.nv = nv; A.nb = std::min(kBatch, m - b);
         A.x0 = (float)ox0; A.y0 = (float)oy0; A.z0 = (float)oz0; A.sx = (float)o->sx; A.sy = (float)o->sy; A.sz = (float)o->sz;
         A.sid = (float)o->sid; A.sdd = (float)o->sdd; A.inv_du = (float)(1.0 / o->du); A.inv_dv = (float)(1.0 / o->dv);
         A.u0 = (float)u0_p; A.v0 = (float)o->v0; A.dbeta = (float)(2.0 * M_PI / n);
@@ -371,7 +423,9 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     mcgpu_set_last_error_(e.msg.c_str());
     rc = -1;
   }
-  for (void* p : {(void*)d_free_raw, (void*)d_in, (void*)d_tmp, (void*)d_vol, (void*)d_h, (void*)d_ky, (void*)d_wdis, (void*)d_wpc, (void*)d_pp})
+  if (plan_fwd) hipfftDestroy(plan_fwd);
+  if (plan_inv) hipfftDestroy(plan_inv);
+  for (void* p : {(void*)d_spec, (void*)d_free_raw, (void*)d_in, (void*)d_tmp, (void*)d_vol, (void*)d_h, (void*)d_ky, (void*)d_wdis, (void*)d_wpc, (void*)d_pp})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {e0, e1, e2, e3})
     if (e) (void)hipEventDestroy(e);
