@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256, 4) void backproject_kernel(float* __restrict__
         if (iv >= 0 && iv < A.nv - 1) {
           const float av = fv - fl;
           const float* r0 = q + (size_t)k * plane + (size_t)iv * A.stride + iu[k];
-          const float v00 = r0[0], v01 = r0[1], v10 = r0[A.stride], v11 = r0[A.stride + 1];
+          float2 lo, hi;  // (iu, iu + 1) of both rows with one 8-byte load each (4-byte aligned: global loads need no more)
+          __builtin_memcpy(&lo, r0, 8);
+          __builtin_memcpy(&hi, r0 + A.stride, 8);
+          const float v00 = lo.x, v01 = lo.y, v10 = hi.x, v11 = hi.y;
           const float top = fmaf(au[k], v01 - v00, v00), bot = fmaf(au[k], v11 - v10, v10);
           acc = fmaf(wg[k], fmaf(av, bot - top, top), acc);
         }
