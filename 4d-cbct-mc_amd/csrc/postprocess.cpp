@@ -7,6 +7,8 @@
 // and, with an air scan, projections_total_normalized = log(gaussian_filter(air, sigma) / total).
 // Here the same numbers are produced straight from the integer tallies (decimal8.hpp), streamed plane by plane
 // into MetaImage files, without the 63 MB-per-projection text detour.
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -134,21 +136,48 @@ void mha_append(MhaStack* s, const float* plane) {
 float mha_finish(MhaStack* s, bool replace_zeros) {
   const float fill = s->min_positive;
   if (replace_zeros && std::isfinite(fill)) {
-    // slice-wise read-modify-write (one seek per slice, not per zero: low-statistics stacks hold millions of zeros)
+    // Slices that hold zeros are read, patched and written back whole (pread/pwrite, several threads: the work is
+    // page-cache copies); a slice with only a handful of zeros gets them patched in place.  The zero positions were
+    // recorded while the planes were written.
     const size_t n = (size_t)s->nx * s->ny;
-    std::vector<unsigned char> dirty((size_t)s->nslices, s->zeros_overflow ? 1 : 0);
-    if (!s->zeros_overflow)
-      for (uint64_t idx : s->zeros) dirty[idx / n] = 1;
-    std::vector<float> buf(n);
-    for (int k = 0; k < s->nslices; ++k) {
-      if (!dirty[k]) continue;
-      fseek(s->fp, s->data_offset + (long)((size_t)k * n * 4), SEEK_SET);
-      if (fread(buf.data(), 4, n, s->fp) != n) continue;  // slice never written: reported below
-      for (float& v : buf)
-        if (v == 0.0f) v = fill;
-      fseek(s->fp, s->data_offset + (long)((size_t)k * n * 4), SEEK_SET);
-      fwrite(buf.data(), 4, n, s->fp);
+    const size_t kFewZeros = 64;
+    std::vector<uint32_t> count((size_t)s->nslices, 0);
+    std::vector<size_t> first((size_t)s->nslices + 1, 0);
+    if (!s->zeros_overflow) {
+      if (!s->have.empty()) std::sort(s->zeros.begin(), s->zeros.end());  // slices written by index: any order
+      for (uint64_t idx : s->zeros) ++count[idx / n];
+      for (int k = 0; k < s->nslices; ++k) first[(size_t)k + 1] = first[(size_t)k] + count[k];
     }
+    fflush(s->fp);
+    const int fd = fileno(s->fp);
+    std::vector<int> dirty;
+    for (int k = 0; k < s->nslices; ++k)
+      if (s->zeros_overflow || count[k] > 0) dirty.push_back(k);
+    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), dirty.size()}));
+    std::vector<int> failed((size_t)nthreads, 0);
+    auto work = [&](int t) {
+      std::vector<float> buf;
+      for (size_t d = (size_t)t; d < dirty.size(); d += (size_t)nthreads) {
+        const int k = dirty[d];
+        const off_t at = (off_t)(s->data_offset + (long)((size_t)k * n * 4));
+        if (!s->zeros_overflow && count[k] <= kFewZeros) {
+          for (size_t z = first[(size_t)k]; z < first[(size_t)k + 1]; ++z)
+            if (pwrite(fd, &fill, 4, (off_t)(s->data_offset + (long)(s->zeros[z] * 4))) != 4) failed[(size_t)t] = 1;
+          continue;
+        }
+        buf.resize(n);
+        if (pread(fd, buf.data(), n * 4, at) != (ssize_t)(n * 4)) continue;  // slice never written: reported below
+        for (float& v : buf)
+          if (v == 0.0f) v = fill;
+        if (pwrite(fd, buf.data(), n * 4, at) != (ssize_t)(n * 4)) failed[(size_t)t] = 1;
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (int f : failed)
+      if (f) throw Error(-3, "!!ERROR!! short write to " + s->path);
   }
   const bool complete = s->written == s->nslices;
   const std::string path = s->path;

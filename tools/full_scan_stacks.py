@@ -1,0 +1,12 @@
+"""The whole bench scan (894 projections of 1e8 histories) with the three MetaImage stacks written (8.4 GB): end-to-end time."""
+import sys, time, shutil
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import cases
+from pathlib import Path
+eng = cases.pkg.engine
+out = Path("/tmp/scan_full_stacks"); out.mkdir(exist_ok=True)
+with eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0) as ctx:
+    t0 = time.time()
+    r = ctx.run_scan(mode="fast", histories=int(1e8), crop_nx=1024, write_stacks=True, output_folder=out, pixel_spacing=(0.776, 0.776))
+    print({k: round(v, 3) if isinstance(v, float) else v for k, v in r.items() if k != "zero_replacement"}, "wall", round(time.time() - t0, 2))
+shutil.rmtree(out, ignore_errors=True)
