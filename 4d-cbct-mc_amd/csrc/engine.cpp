@@ -81,6 +81,7 @@ struct DeviceModel {
   unsigned short* sig_mid = nullptr;  // cross-section brackets (FAST flight step), see upload_model
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
+  int sched[5] = {24, 8, 36, 12, 24};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
@@ -778,8 +779,8 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       {  // FAST scheduling knobs live in TrackCold; the environment may change them between launches (tuning sweeps)
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         TrackCold& ch = D.cold_host;
-        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", 24), env_int("MCGPU_THRESH_RAYLEIGH", 8), env_int("MCGPU_THRESH_NEW", 36),
-                              std::max(1, env_int("MCGPU_FLYABLE_LOW", 12)), std::max(1, env_int("MCGPU_SWAP_BATCH", 24))};
+        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", D.sched[0]), env_int("MCGPU_THRESH_RAYLEIGH", D.sched[1]), env_int("MCGPU_THRESH_NEW", D.sched[2]),
+                              std::max(1, env_int("MCGPU_FLYABLE_LOW", D.sched[3])), std::max(1, env_int("MCGPU_SWAP_BATCH", D.sched[4]))};
         if (ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
             ch.swap_batch != want5[4]) {
           ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];
@@ -817,6 +818,18 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
   }
   HIP_TRY(hipEventRecord(D.ev_stop, stream));
   D.timed = true;
+  return 0;
+  ABI_END
+}
+
+int mcgpu_set_fast_schedule(mcgpu_ctx* ctx, int thresh_compton, int thresh_rayleigh, int thresh_new, int flyable_low, int swap_batch) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_set_fast_schedule: no device context");
+  require(thresh_compton >= 1 && thresh_rayleigh >= 1 && thresh_new >= 1 && flyable_low >= 1 && swap_batch >= 1 && thresh_compton <= 64 &&
+              thresh_rayleigh <= 64 && thresh_new <= 64 && flyable_low <= 64 && swap_batch <= 64,
+          -2, "!!ERROR!! mcgpu_set_fast_schedule: thresholds are lane counts in 1..64");
+  const int v[5] = {thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch};
+  for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = v[k];
   return 0;
   ABI_END
 }

@@ -185,6 +185,36 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         fflush(stdout);
       }
     }
+    // FAST batching thresholds: a few presets timed with throw-away launches on the first simulated projection (the best
+    // one differs between geometries by 5-7 %; the tallies do not depend on the choice).  Skipped for short scans and when
+    // the environment pins the knobs.
+    if (mode == MCGPU_MODE_FAST && total >= 20000000ULL && !getenv("MCGPU_THRESH_COMPTON") && !getenv("MCGPU_THRESH_NEW") &&
+        !getenv("MCGPU_SWAP_BATCH") && !getenv("MCGPU_NO_AUTOTUNE")) {
+      static const int presets[3][5] = {{24, 8, 36, 12, 24}, {32, 8, 44, 12, 24}, {24, 8, 36, 12, 16}};
+      const unsigned long long probe = 6000000ULL;
+      int best = 0;
+      float best_ms = 1e30f;
+      for (int c = 0; c < 3; ++c) {
+        ABI_OK(mcgpu_set_fast_schedule(ctx, presets[c][0], presets[c][1], presets[c][2], presets[c][3], presets[c][4]));
+        float ms = 0.f, fastest = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {  // the first launch of a preset pays the parameter upload
+          ABI_OK(mcgpu_launch_projection(ctx, first + (count > 0 ? sim[0] : 0), mode, (int)seed, 0, probe, (int)hpt, D[0].image[0], D[0].stream));
+          ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
+          if (rep > 0 && ms < fastest) fastest = ms;
+        }
+        if (fastest < best_ms) { best_ms = fastest; best = c; }
+      }
+      for (int g = 0; g < n_ctx; ++g)
+        ABI_OK(mcgpu_set_fast_schedule(D[g].ctx, presets[best][0], presets[best][1], presets[best][2], presets[best][3], presets[best][4]));
+      HIP_OK(hipSetDevice(D[0].dev));
+      HIP_OK(hipMemsetAsync(D[0].image[0], 0, words * 8, D[0].stream));
+      ABI_OK(mcgpu_dose_clear(ctx));
+      if (opt->progress) {
+        printf("       FAST batching preset %d of 3 (thresholds %d/%d/%d, %d, %d)\n", best + 1, presets[best][0], presets[best][1], presets[best][2],
+               presets[best][3], presets[best][4]);
+        fflush(stdout);
+      }
+    }
     for (int g = 0; g < n_ctx; ++g) { D[g].lo = units * g / n_ctx; D[g].hi = units * (g + 1) / n_ctx; }
     for (int b = 0; b < 2; ++b) {
       HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume",
-    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_fdk_reconstruct",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule",
 )
 
 

@@ -92,6 +92,12 @@ int mcgpu_last_kernel_ms(mcgpu_ctx *ctx, float *ms);
 /* Scheduler statistics accumulated by MCGPU_MODE_FAST_STATS launches: out8 = {wave loop iterations, sum of flying
  * lanes, Compton rounds, Compton lanes, Rayleigh rounds, Rayleigh lanes, tally+source rounds, their lanes}. */
 int mcgpu_scheduler_stats(mcgpu_ctx *ctx, unsigned long long *out8, int reset);
+/* Batching thresholds of the FAST kernel, in lanes of a wave64: pending Compton / Rayleigh / tally+source histories that
+ * trigger a batch, the number of lanes able to fly below which every well-populated kind is served, and how many lanes park
+ * between two scheduling points.  Results never depend on them (per-history RNG streams, integer tallies); speed does, by a
+ * few percent between geometries.  mcgpu_run_scan picks among a few presets with short throw-away launches unless
+ * MCGPU_THRESH_* / MCGPU_FLYABLE_LOW / MCGPU_SWAP_BATCH are set in the environment (those always win). */
+int mcgpu_set_fast_schedule(mcgpu_ctx *ctx, int thresh_compton, int thresh_rayleigh, int thresh_new, int flyable_low, int swap_batch);
 /* The same with the full counter set (up to 16): 8 = scheduling points, 9/10 = register<->LDS-slot exchange rounds /
  * lanes that bring a flying history in, 11 = scheduling points in drain mode. */
 int mcgpu_scheduler_stats_ex(mcgpu_ctx *ctx, unsigned long long *out, int capacity, int reset);
