@@ -93,6 +93,24 @@ def pmc_traffic(kernel_ms: float):
     return (2.0 * fetch + write) * 1024.0, d.get("_note", f.name)
 
 
+def valu_issue(kernel_ms: float):
+    """VALU issue rate of the tracking kernel against the rate a dense dependent-FMA kernel reaches on the same chip
+    (tools/micro/exec_skip.hip: 5.24e9 wave-instructions on 1024 SIMDs in 6.39 ms with 64 active lanes, in 4.96-5.31 ms with
+    16-32 active lanes; the tracking kernel runs at 36 % lane utilisation).  SQ_INSTS_VALU from the committed PMC summary."""
+    f = ROOT / "profiles" / "pmc_summary_latest.json"
+    if not f.exists():
+        return None
+    d = json.loads(f.read_text())
+    if "SQ_INSTS_VALU" not in d:
+        return None
+    insts = d["SQ_INSTS_VALU"]["mean_per_dispatch"]
+    achieved = insts / 1024.0 / (kernel_ms * 1e6)  # wave-instructions per ns and SIMD
+    peak = 5.24e9 / 1024.0 / 5.1e6               # measured, 16-32 active lanes
+    return {"valu_wave_instructions_per_launch": insts, "achieved_per_ns_per_simd": achieved, "measured_peak_per_ns_per_simd": peak,
+            "frac": achieved / peak, "lane_utilisation": d["SQ_THREAD_CYCLES_VALU"]["mean_per_dispatch"] / d["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / 64.0
+            if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d else None}
+
+
 def end_to_end_scan(ctx, H, workdir, n=12):
     """The pipelined scan driver (track -> finalize -> pinned copy -> writer thread) with the three MetaImage stacks
     written to disk: per-projection wall time including output, reported beside the kernel-only figure."""
@@ -236,6 +254,7 @@ def main():
             # tools/micro/atomic_rate.hip on MI355X = 2.37e10/s; detected photons per history of this workload = 0.754
             "atomic_roofline": {"bound": "scattered 64-bit atomic adds", "achieved": 0.754 * H / (k_ms * 1e-3) / 1e9, "peak": 23.7,
                                 "unit": "Gatomic/s", "frac": 0.754 * H / (k_ms * 1e-3) / 23.7e9},
+            "valu_issue": valu_issue(k_ms),
             "timing": {"prepare_inputs_s": t_prep, "load_and_upload_s": t_load},
             "check": {"detected_energy_units_last_projection": detected},
         }
