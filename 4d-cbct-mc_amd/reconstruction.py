@@ -97,6 +97,11 @@ def create_geometry(n_projections: int, start_angle: float = 270.0,
     return g
 
 
+def save_geometry(geometry: CircularGeometry, output_filepath) -> Path:
+    """cbctmc/forward_projection.py:198-205 (`save_geometry(geometry, path)`): RTK circular-geometry XML."""
+    return geometry.write(output_filepath)
+
+
 class _FdkOptions(C.Structure):
     _fields_ = [("n_proj", C.c_int), ("nu", C.c_int), ("nv", C.c_int), ("du", C.c_double), ("dv", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("sid", C.c_double), ("sdd", C.c_double), ("gantry_deg", C.POINTER(C.c_double)), ("proj_offset_x", C.POINTER(C.c_double)),
