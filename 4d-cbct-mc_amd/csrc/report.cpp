@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -151,8 +152,32 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
   }
   double energy_integral = 0.0, maximum = -100.0;
   long max_pixel = 0;
+  {
+    // the 63 MB of text go to the file in parallel too: every band is written at its own offset (pwrite); a serial fwrite of
+    // the bands was 15 of the 20 ms a projection cost
+    fflush(fp);
+    const int fd = fileno(fp);
+    std::vector<off_t> at((size_t)T + 1, (off_t)ftello(fp));
+    for (int t = 0; t < T; ++t) at[(size_t)t + 1] = at[(size_t)t] + (off_t)chunks[t].size();
+    std::vector<int> bad((size_t)T, 0);
+    auto put = [&](int t) {
+      size_t done = 0;
+      while (done < chunks[t].size()) {
+        const ssize_t k = pwrite(fd, chunks[t].data() + done, chunks[t].size() - done, at[(size_t)t] + (off_t)done);
+        if (k <= 0) { bad[(size_t)t] = 1; return; }
+        done += (size_t)k;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(put, t);
+    put(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; ++t)
+      if (bad[(size_t)t]) { fclose(fp); throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!"); }
+    fseeko(fp, at[(size_t)T], SEEK_SET);
+  }
   for (int t = 0; t < T; ++t) {
-    bytes += fwrite(chunks[t].data(), 1, chunks[t].size(), fp);
+    bytes += chunks[t].size();
     energy_integral += integral[t];  // NB: summed per band; the footer's %.3lf is insensitive to the order
     if (maxval[t] > maximum) { maximum = maxval[t]; max_pixel = maxpix[t]; }
   }
