@@ -39,12 +39,23 @@ inline char* put_fixed8(char* out, double v) {
       uint64_t frac = (uint64_t)fl + (rem > 0.5 ? 1u : 0u);
       uint64_t iv = (uint64_t)ip;
       if (frac >= 100000000ull) { frac -= 100000000ull; ++iv; }
-      char tmp[24];
-      int n = 0;
-      do { tmp[n++] = (char)('0' + iv % 10); iv /= 10; } while (iv);
-      while (n) *out++ = tmp[--n];
+      // two digits per step from a 200-byte table
+      static const char kPairs[201] =
+          "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869"
+          "707172737475767778798081828384858687888990919293949596979899";
+      if (iv < 10) *out++ = (char)('0' + iv);
+      else {
+        char tmp[24];
+        int n = 0;
+        while (iv >= 100) { const unsigned r = (unsigned)(iv % 100); iv /= 100; tmp[n++] = kPairs[2 * r + 1]; tmp[n++] = kPairs[2 * r]; }
+        if (iv >= 10) { tmp[n++] = kPairs[2 * iv + 1]; tmp[n++] = kPairs[2 * iv]; }
+        else tmp[n++] = (char)('0' + iv);
+        while (n) *out++ = tmp[--n];
+      }
       *out++ = '.';
-      for (int k = 7; k >= 0; --k) { out[k] = (char)('0' + frac % 10); frac /= 10; }
+      const unsigned hi = (unsigned)(frac / 10000), lo = (unsigned)(frac % 10000);
+      const unsigned a = hi / 100, b = hi % 100, c = lo / 100, d = lo % 100;
+      memcpy(out, kPairs + 2 * a, 2); memcpy(out + 2, kPairs + 2 * b, 2); memcpy(out + 4, kPairs + 2 * c, 2); memcpy(out + 6, kPairs + 2 * d, 2);
       return out + 8;
     }
   }
