@@ -16,6 +16,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 #include <unordered_map>
@@ -125,14 +127,35 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
   int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   T = std::min(T, nz);
   if (npix < 65536) T = 1;
-  std::vector<std::string> chunks(T);
+  // text of band t: chunks[t] is a view (pointer, length) into a buffer that is allocated uninitialised (a std::string
+  // would first zero-fill its 28-bytes-per-number capacity: 160 MB per projection)
+  // The buffers are recycled between calls (BandPool): fresh 10 MB allocations per band and projection cost more in page
+  // faults than the formatting itself.
+  struct Band { std::vector<char>* mem = nullptr; size_t len = 0; const char* data() const { return mem->data(); } size_t size() const { return len; } };
+  struct BandPool {
+    std::mutex mu;
+    std::vector<std::vector<char>*> free_list;
+    std::vector<char>* take(size_t bytes) {
+      std::vector<char>* v = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!free_list.empty()) { v = free_list.back(); free_list.pop_back(); }
+      }
+      if (!v) v = new std::vector<char>();
+      if (v->size() < bytes) v->resize(bytes);  // grows (and zero-fills) only the first time
+      return v;
+    }
+    void give(std::vector<char>* v) { std::lock_guard<std::mutex> lk(mu); free_list.push_back(v); }
+  };
+  static BandPool pool;
+  std::vector<Band> chunks(T);
   std::vector<double> integral(T, 0.0), maxval(T, -100.0);
   std::vector<long> maxpix(T, 0);
   auto work = [&](int t) {
     const int z0 = (int)((long)nz * t / T), z1 = (int)((long)nz * (t + 1) / T);
-    std::string& out = chunks[t];
-    out.resize((size_t)(z1 - z0) * ((size_t)nx * 4 * 28 + 1) + 64);
-    char* w = &out[0];
+    Band& out = chunks[t];
+    out.mem = pool.take((size_t)(z1 - z0) * ((size_t)nx * 4 * 28 + 1) + 64);
+    char* w = out.mem->data();
     double integ = 0.0, mx = -100.0;
     long mp = 0;
     for (int j = z0; j < z1; ++j) {
@@ -150,7 +173,7 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
       }
       *w++ = '\n';
     }
-    out.resize((size_t)(w - &out[0]));
+    out.len = (size_t)(w - out.mem->data());
     integral[t] = integ;
     maxval[t] = mx;
     maxpix[t] = mp;
@@ -188,6 +211,7 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
     fseeko(fp, at[(size_t)T], SEEK_SET);
   }
   for (int t = 0; t < T; ++t) {
+    pool.give(chunks[t].mem);
     bytes += chunks[t].size();
     energy_integral += integral[t];  // NB: summed per band; the footer's %.3lf is insensitive to the order
     if (maxval[t] > maximum) { maximum = maxval[t]; max_pixel = maxpix[t]; }
