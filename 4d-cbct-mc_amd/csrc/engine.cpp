@@ -201,7 +201,21 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     int k = 2;
     auto nb = [&](int n, int sh) { return (n + (1 << sh) - 1) >> sh; };
     const char* mb = getenv("MCGPU_MAX_BRICKS");  // tuning knob: a coarser grid frees LDS
-    const long max_bricks = mb ? std::min<long>(std::max<long>(atol(mb), 1), kMaxBricks) : kMaxBricks;
+    long max_bricks = mb ? std::min<long>(std::max<long>(atol(mb), 1), kMaxBricks) : kMaxBricks;
+    {
+      // The FAST kernel wants two 1024-thread workgroups per CU, i.e. an LDS image of at most 80 KB.  Everything but the
+      // brick grid is fixed by the materials in use (22 tissue materials: 458 Compton shells = 7.3 KB against 1.4 KB for
+      // the Catphan set), so the grid gets what is left after the tables, the history slots and a coarse bracket table.
+      int shells = 0;
+      for (int m = 0; m < kMaxMaterials; ++m)
+        if (D.compact_of[m] >= 0) shells += std::min(H.mat.noscco[m], kMaxShells);
+      const int ns = std::min(H.spectrum.num_bins + 1, kMaxSpectrumBins) + 1;
+      const int nc = (nv + (1 << 9) - 1) >> 9;  // brackets no coarser than 2^9 table bins
+      const long fixed = std::max(shells, 1) * 16 + std::max(nmat, 1) * 8 + ns * 10 + (16 + (long)index_of.size()) * 8 + 2 * kMaxMaterials * 8 +
+                         (long)kSlotWords * kPoolBlockThreads * 4 + nc * nmat * 2 + nc * 4 + 12 * 16;
+      const long left = 160 * 1024 / 2 - fixed;
+      if (left > 0) max_bricks = std::min(max_bricks, std::max(2 * left, 512L));
+    }
     while ((long)nb(nx, k) * nb(ny, k) * nb(nz, k) > max_bricks) ++k;
     D.brick_shift = k;
     D.brick_n[0] = nb(nx, k); D.brick_n[1] = nb(ny, k); D.brick_n[2] = nb(nz, k);

@@ -806,12 +806,14 @@ void load_material_files(const std::vector<std::string>& files, const VoxelGrid&
     next_line(line);
     for (int i = 0; i < nray; ++i) {
       const int bin = kRayleighPoints * mat + i;
-      int itl = 0, itu = 0;
+      // ITL / ITU are read as numbers and truncated: the reference's aluminium table writes them as "1.0 4.0", on which
+      // the reference's unchecked "%d %d" stops after "1" and leaves ITU uninitialised (:2387-2392; DESIGN.md deviation 10)
+      double itl = 0.0, itu = 0.0;
       next_line(line);
-      if (sscanf(line.c_str(), "  %e  %e  %e  %e  %d  %d", &t.xco[bin], &t.pco[bin], &t.aco[bin], &t.bco[bin], &itl, &itu) != 6)
+      if (sscanf(line.c_str(), "  %e  %e  %e  %e  %lf  %lf", &t.xco[bin], &t.pco[bin], &t.aco[bin], &t.bco[bin], &itl, &itu) != 6)
         fail(-2, "!!ERROR!! Could not read Rayleigh sampling row %d in '%s'.", i, files[mat].c_str());
-      t.itlco[bin] = (uint8_t)itl;
-      t.ituco[bin] = (uint8_t)itu;
+      t.itlco[bin] = (uint8_t)(int)itl;
+      t.ituco[bin] = (uint8_t)(int)itu;
     }
     // Compton shells (:2397-2426)
     ok = false;
@@ -826,9 +828,8 @@ void load_material_files(const std::vector<std::string>& files, const VoxelGrid&
     next_line(line);
     for (int i = 0; i < nsh; ++i) {
       const int bin = mat + i * kMaxMaterials;
-      int kz, ks;
-      next_line(line);
-      if (sscanf(line.c_str(), " %e  %e  %e  %d  %d", &t.fco[bin], &t.uico[bin], &t.fj0[bin], &kz, &ks) != 5)
+      next_line(line);  // KZCO and KSCO (unused by the reference too, :2424-2426) may be written as "13.0 0.0"
+      if (sscanf(line.c_str(), " %e  %e  %e", &t.fco[bin], &t.uico[bin], &t.fj0[bin]) != 3)
         fail(-2, "!!ERROR!! Could not read Compton shell %d in '%s'.", i, files[mat].c_str());
     }
   }

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz from the REAL reference (oracle/_ref, built from /root/reference).
 
 Test infrastructure; runs only in the development container (the reference does not exist on the
-GPU box).  Usage:  make -C oracle ref && python oracle/gen_golden.py
+GPU box).  Usage:  make -C oracle ref && python oracle/gen_golden.py [case ...]   (default: every case + the KATs)
 
 Fixtures written (all inputs come from tests/cases.py, so the tests can rebuild the same cases):
   golden/rng_kat.npz        RANECU known answers: init_PRNG seeds, float/double draw sequences, abMODm,
@@ -34,7 +34,8 @@ import cases  # noqa: E402
 import oracle_lib as ol  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
-NBATCH = {"air": 200, "water": 200, "catphan64": 400, "catphan64_ct": 100, "slab_angles": 100, "catphan64_dose": 150, "graded_u16": 100, "graded_raw": 100}
+NBATCH = {"air": 200, "water": 200, "catphan64": 400, "catphan64_ct": 100, "slab_angles": 100, "catphan64_dose": 150, "graded_u16": 100, "graded_raw": 100,
+          "cirs76": 100, "thorax64": 100, "tissue22": 100}
 HPT = 150
 
 
@@ -248,12 +249,14 @@ def main():
         raise SystemExit("oracle/_ref is missing: run `make -C oracle ref` in the development container")
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = ol.Reference()
-    rng_kat(ref)
+    only = sys.argv[1:]
+    if not only:
+        rng_kat(ref)
     with tempfile.TemporaryDirectory() as wd:
         wd = Path(wd)
-        for name in cases.CASES:
+        for name in (only or cases.CASES):
             T = case_fixture(ref, name, wd)
-            if name == "catphan64":
+            if name == "catphan64" and not only:
                 physics_kat(ref, T)
 
 

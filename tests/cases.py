@@ -1,7 +1,7 @@
 """Shared test-case builder (test infrastructure): small geometries + `.in` files on disk.
 
-Material numbering in the reduced cases follows the reference's 22-material order; materials
-without a data fixture get header-only stubs (only their density line is ever read).
+Material numbering in the reduced cases follows the reference's 22-material order; all 22 PENELOPE
+tables of the reference are committed as fixtures (tests/golden/materials/*.mcgpu.xz).
 """
 from __future__ import annotations
 
@@ -26,8 +26,32 @@ materials = pkg.materials
 CACHE = Path(os.environ.get("MCGPU_TEST_CACHE", "/tmp/mcgpu_amd_test_cache"))
 
 
-def material_files():
-    return materials.resolve_material_files([GOLDEN / "materials"], CACHE / "materials")
+def material_files(raw_aluminium=False):
+    """The 22 material files in MC-GPU order.  The reference's aluminium table writes the integer columns ITL/ITU (and
+    KZCO/KSCO) as "1.0 4.0", on which the reference's unchecked `sscanf("%d %d")` leaves ITU uninitialised
+    (MC-GPU_v1.3.cu:2387-2392; DESIGN.md deviation 10).  So that the reference build and the engine read the SAME
+    numbers in the table-parity tests, the cases use a copy with those columns rewritten as integers;
+    `raw_aluminium=True` gives the file as shipped (test_formats_and_abi.py checks both parse to the same tables)."""
+    paths = materials.resolve_material_files([GOLDEN / "materials"], CACHE / "materials")
+    if raw_aluminium:
+        return paths
+    k = materials.material_number("aluminium") - 1
+    fixed = paths[k].with_name("aluminium__5_125kev.intcols.mcgpu")
+    if not fixed.is_file():
+        out, section = [], None
+        for line in paths[k].read_text().split("\n"):
+            if line.startswith("#"):
+                section = "rita" if "COMMON/CGRA/" in line else "shells" if "COMMON/CGCO/" in line else section
+            elif line.strip() and section in ("rita", "shells"):
+                t = line.split()
+                keep = 4 if section == "rita" else 3
+                line = " ".join(t[:keep] + [str(int(float(v))) for v in t[keep:]])
+            out.append(line)
+        tmp = fixed.with_name(fixed.name + f".tmp{os.getpid()}")
+        tmp.write_text("\n".join(out))
+        os.replace(tmp, fixed)
+    paths[k] = fixed
+    return paths
 
 
 def spectrum_file():
@@ -74,6 +98,30 @@ def _graded(n_levels):
     return make
 
 
+def _cirs_small():
+    """BASELINE configs 3/5 workload, reduced: the bundled CIRS thorax phantom with its tumour insert, every 4th voxel at
+    4 mm -> 77 x 75 x 38 (non-square slices: the source sits 4 mm off the rotated volume's x centre).
+    Materials: air, h2o at 0.207 (lung equivalent), soft_tissue, red_marrow (a shell above the 5 keV cut-off), bone_020/050/100."""
+    return geometry.MCCIRSPhantomGeometry.from_base_geometry().place_insert().downsample(4)
+
+
+def _thorax_small():
+    """BASELINE config 4 workload, reduced: patient-like thorax of 14 tissue classes (incl. blood: 40 shells = MAX_SHELLS)."""
+    return geometry.MCThoraxLikeGeometry(shape=(64, 64, 32), image_spacing=(8.0, 8.0, 8.0))
+
+
+def _tissue22():
+    """All 22 materials of the reference in one volume (each a 10 x 10 x 11 voxel block in a water tank, nominal densities):
+    the full LDS layout (22 shell tables) and every PENELOPE table fixture are exercised."""
+    g = geometry.MCBoxGeometry(shape=(44, 42, 26), image_spacing=(8.0, 8.0, 8.0), material="h2o")
+    for k, ident in enumerate(materials.MATERIAL_IDS):
+        i, j, l = k % 4, (k // 4) % 3, k // 12
+        sl = (slice(2 + 10 * i, 12 + 10 * i), slice(1 + 13 * j, 14 + 13 * j), slice(2 + 11 * l, 13 + 11 * l))
+        g.materials[sl] = materials.material_number(ident)
+        g.densities[sl] = np.float32(materials.MATERIALS_125KEV[ident])
+    return g
+
+
 SMALL_DET = dict(n_detector_pixels=(231, 96), detector_size=(717.024, 297.984))
 CASES = {
     "air": (_air, dict(n_projections=1, n_histories=300_000, **SMALL_DET)),
@@ -83,6 +131,9 @@ CASES = {
     "slab_angles": (_slab_nonsquare, dict(projection_angles=[270.0, 300.5, 45.25], n_histories=60_000, **SMALL_DET)),
     "graded_u16": (_graded(3000), dict(n_projections=2, angle_between_projections=77.0, n_histories=60_000, **SMALL_DET)),
     "graded_raw": (_graded(80000), dict(n_projections=1, n_histories=60_000, **SMALL_DET)),
+    "cirs76": (_cirs_small, dict(n_projections=3, angle_between_projections=120.0, n_histories=60_000, **SMALL_DET)),
+    "thorax64": (_thorax_small, dict(n_projections=2, angle_between_projections=90.0, n_histories=60_000, **SMALL_DET)),
+    "tissue22": (_tissue22, dict(n_projections=2, angle_between_projections=45.0, n_histories=60_000, **SMALL_DET)),
     # both dose tallies on (the reference template keeps them off): ROI in 1-based inclusive voxel indices; two
     # projections, because the dose arrays accumulate over the scan
     "catphan64_dose": (_catphan_small, dict(n_projections=2, angle_between_projections=90.0, n_histories=60_000,

@@ -185,3 +185,25 @@ def test_binary_voxel_sidecar_equals_text_parse(engine, tmp_path):
     with pytest.raises(engine.EngineError) as e:
         engine.create(b / "input.in", device=-1)
     assert "ERROR" in e.value.message
+
+
+def test_aluminium_table_with_float_formatted_integer_columns(engine, tmp_path):
+    """The reference's aluminium table writes ITL/ITU and KZCO/KSCO as "1.0 4.0".  The reference reads them with an
+    unchecked sscanf("%d %d") that stops at the '.', leaving ITU uninitialised (MC-GPU_v1.3.cu:2387-2392); the engine
+    reads the numbers that are written (DESIGN.md deviation 10): the file as shipped must give exactly the tables of a
+    copy whose columns are spelled as integers -- which is also what the reference build reads from that copy
+    (test_host_tables.py, case tissue22)."""
+    raw_files = cases.material_files(raw_aluminium=True)
+    k = cases.materials.material_number("aluminium") - 1
+    text = raw_files[k].read_text()
+    assert re.search(r"^0\.0 0\.0 \S+ \S+ 1\.0 4\.0$", text, re.M)
+    g = cases.geometry.MCBoxGeometry(shape=(6, 6, 6), image_spacing=(10.0, 10.0, 10.0), material="aluminium")
+    tabs = []
+    for sub, files in (("raw", raw_files), ("int", cases.material_files())):
+        sim = cases.simulation.MCSimulation(g, files, cases.spectrum_file(), n_projections=1, n_histories=1000, **cases.SMALL_DET)
+        with engine.create(sim.prepare_simulation(tmp_path / sub), device=-1) as ctx:
+            tabs.append({n: ctx.host_table(n).copy() for n in ("itlco", "ituco", "xco", "pco", "aco", "bco", "fco", "uico", "fj0", "noscco", "mfp_a")})
+    for n in tabs[0]:
+        assert np.array_equal(tabs[0][n], tabs[1][n]), n
+    itu = tabs[0]["ituco"].reshape(25, 128)[k]
+    assert itu[0] == 4 and itu.max() == 128 and tabs[0]["noscco"].view("<i4")[k] == 5

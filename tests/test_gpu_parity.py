@@ -13,7 +13,7 @@ import parity
 pytestmark = pytest.mark.gpu
 
 CASE_BATCHES = [("air", 256), ("water", 512), ("catphan64", 512), ("catphan64_ct", 256), ("slab_angles", 256), ("graded_u16", 256),
-                ("graded_raw", 256)]
+                ("graded_raw", 256), ("cirs76", 256), ("thorax64", 256), ("tissue22", 256)]
 
 
 @pytest.fixture(scope="module")
@@ -94,7 +94,18 @@ def test_volume_storage_kinds_are_exercised(gpu_engine, case_dir):
     assert kinds == {"catphan64": 0, "graded_u16": 1, "graded_raw": 2}
 
 
-@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw"])
+def test_lds_image_keeps_two_workgroups_per_cu_with_all_22_materials(gpu_engine, case_dir):
+    """458 Compton shells (22 materials; blood alone has MAX_SHELLS = 40) take 7.3 KB of LDS against 1.4 KB for the Catphan
+    set: the host sizes the brick grid and the bracket table so that the FAST kernel's image stays within 80 KB."""
+    for name, nmat in (("tissue22", 22), ("thorax64", 14), ("cirs76", 7)):
+        with gpu_engine.create(case_dir(name), device=0) as ctx:
+            assert ctx.geti("num_materials_used") == nmat
+            ctx.run_projection(0, 200_000, mode="fast", seed=1)
+            assert ctx.geti("lds_bytes_fast") <= 80 * 1024 and ctx.geti("blocks_per_cu") == 2, name
+            assert ctx.geti("sigma_bracket_shift") >= 6, name
+
+
+@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw", "cirs76", "thorax64", "tissue22"])
 def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
     """FAST vs oracle (LIBM math = the reference's own arithmetic): every class image, per pixel."""
     with gpu_engine.create(case_dir(name), device=0) as ctx:
