@@ -457,7 +457,14 @@ static inline void tally_add(uint64_t *word, unsigned long long v, int shared)
   else *word += (uint64_t)v;
 }
 
-static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state, uint64_t *image, const src_t *S, const det_t *D,
+static inline void tally_pixel(uint64_t *image, uint64_t *w2, int word, float energy, int shared)
+{
+  const unsigned long long w = (unsigned long long)(energy * 100.0f + 0.5f);
+  tally_add(&image[word], w, shared);
+  if (w2) tally_add(&w2[word], (w >> 10) * (w >> 10), shared);
+}
+
+static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state, uint64_t *image, uint64_t *w2, const src_t *S, const det_t *D,
                         oracle_counters *C, int shared)
 {
   float dist, rot;
@@ -475,7 +482,7 @@ static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state,
       rot = D->rot_inv[6] * pos->x + D->rot_inv[7] * pos->y + D->rot_inv[8] * pos->z;
       float pz = floor((rot - D->corner_min_rotated_to_Y.z) * D->inv_pixel_size_Z);
       if ((pz > -0.1f) && (pz < (D->num_pixels_y - 0.1f))) {
-        tally_add(&image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)], (unsigned long long)(energy * 100.0f + 0.5f), shared);
+        tally_pixel(image, w2, (int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f), energy, shared);
         C->tally_hits++;
       }
     }
@@ -486,7 +493,7 @@ static void tally_image(float energy, f3 *pos, const f3 *dir, int scatter_state,
     if ((px > -0.1f) && (px < (D->num_pixels_x - 0.1f))) {
       float pz = floor((pos->z + dist * dir->z - D->corner_min_rotated_to_Y.z) * D->inv_pixel_size_Z);
       if ((pz > -0.1f) && (pz < (D->num_pixels_y - 0.1f))) {
-        tally_add(&image[(int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f)], (unsigned long long)(energy * 100.0f + 0.5f), shared);
+        tally_pixel(image, w2, (int)(((float)scatter_state) * D->total_num_pixels + px + pz * D->num_pixels_x + 0.0001f), energy, shared);
         C->tally_hits++;
       }
     }
@@ -594,7 +601,7 @@ static void track_batch(const oracle_tables *T, int batch, int hpt, int num_p, i
       if (randno < -0.001f) tally_dose(T, -1.0f * randno, mat, &pos, shared);  /* K.cu:356-367 */
       if (index < 0) break;
     }
-    if (index > -1) tally_image(energy, &pos, &dir, scatter_state, image, S, D, C, shared);
+    if (index > -1) tally_image(energy, &pos, &dir, scatter_state, image, T->image_w2, S, D, C, shared);
   }
 }
 

@@ -35,7 +35,7 @@ class OracleTables(C.Structure):
         ("fco", C.c_void_p), ("uico", C.c_void_p), ("fj0", C.c_void_p), ("noscco", C.c_void_p),
         ("num_bins_espc", C.c_int), ("espc", C.c_void_p), ("espc_cutoff", C.c_void_p), ("espc_alias", C.c_void_p),
         ("source_data", C.c_void_p), ("detector_data", C.c_void_p),
-        ("dose_roi", C.c_int * 6), ("voxels_edep", C.c_void_p), ("materials_dose", C.c_void_p),
+        ("dose_roi", C.c_int * 6), ("voxels_edep", C.c_void_p), ("materials_dose", C.c_void_p), ("image_w2", C.c_void_p),
     ]
 
 
@@ -100,7 +100,7 @@ class TableSet:
         t.size_bbox = (C.c_float * 3)(*self.size_bbox)
         t.num_values, t.e0, t.ide, t.num_bins_espc = self.num_values, float(self.e0), float(self.ide), self.num_bins_espc
         t.dose_roi = (C.c_int * 6)(32500, -32500, 32500, -32500, 32500, -32500)
-        t.voxels_edep, t.materials_dose = None, None
+        t.voxels_edep, t.materials_dose, t.image_w2 = None, None, None
         self.ct = t
         self.dose_voxels = self.dose_materials = None
 
@@ -128,13 +128,24 @@ class TableSet:
     def image_size(self):
         return 4 * int(self.detector[0]["total_num_pixels"])
 
-    def track(self, num_p, seed, batch0, nbatches, hpt, math_mode=MATH_LIBM, n_threads=1, image=None, counters=None):
+    def track(self, num_p, seed, batch0, nbatches, hpt, math_mode=MATH_LIBM, n_threads=1, image=None, counters=None, w2=None):
+        """`w2` (uint64 array like the image): also accumulate the squared tally weights, units (1024 x 0.01 eV)^2."""
         if image is None:
             image = np.zeros(self.image_size(), dtype=np.uint64)
         cnt = counters if counters is not None else OracleCounters()
-        oracle().oracle_track(C.byref(self.ct), num_p, seed, batch0, nbatches, hpt, image.ctypes.data, math_mode, n_threads,
-                              C.byref(cnt))
+        self.ct.image_w2 = w2.ctypes.data if w2 is not None else None
+        try:
+            oracle().oracle_track(C.byref(self.ct), num_p, seed, batch0, nbatches, hpt, image.ctypes.data, math_mode, n_threads,
+                                  C.byref(cnt))
+        finally:
+            self.ct.image_w2 = None
         return image, cnt
+
+    def track_with_variance(self, num_p, seed, batch0, nbatches, hpt, math_mode=MATH_LIBM, n_threads=1):
+        """(image, sum of squared weights in the image's units squared as float64, counters)."""
+        w2 = np.zeros(self.image_size(), dtype=np.uint64)
+        image, cnt = self.track(num_p, seed, batch0, nbatches, hpt, math_mode, n_threads, w2=w2)
+        return image, w2.astype(np.float64) * (1024.0 ** 2), cnt
 
 
 class Reference:

@@ -27,15 +27,36 @@ def tables_from_context(ctx) -> ol.TableSet:
                        ctx.geti("num_spectrum_bins"))
 
 
-def poisson_z(img_a: np.ndarray, n_a: int, img_b: np.ndarray, n_b: int, min_counts: float = 30.0):
-    """Per-pixel z-scores between two energy-weighted tallies (uint64, units of 0.01 eV) from n_a / n_b
-    histories.  Variance model: compound Poisson, var(sum w) ~= sum w^2 ~= mean_w * sum w, with mean_w
-    estimated per image class from the data (energy per detected photon ~ 6e6 units)."""
-    a = img_a.astype(np.float64) / n_a
-    b = img_b.astype(np.float64) / n_b
-    w = 6.0e6  # typical tally weight (60 keV * 100); conservative: real weights are <= 1.25e7
-    var = (img_a.astype(np.float64) * w * 1.6) / n_a ** 2 + (img_b.astype(np.float64) * w * 1.6) / n_b ** 2
-    mask = (img_a.astype(np.float64) / w >= min_counts) & (img_b.astype(np.float64) / w >= min_counts)
+def measured_z(img_a: np.ndarray, n_a: int, img_b: np.ndarray, w2_b: np.ndarray, n_b: int, min_hits: float = 30.0, w2_a=None):
+    """Per-word z-scores between two energy-weighted tallies (units of 0.01 eV) of n_a / n_b histories, with MEASURED
+    variances.  A tally word is a sum over histories of a weight w_i (0 for most): var(sum) = n (E[w^2] - E[w]^2)
+    = sum w^2 - (sum w)^2 / n.  `w2_b` is the sum of squared weights tallied beside `img_b` (oracle_lib.track_with_variance).
+    Sample a (the GPU's, which tallies no squares) gets its sum of squares from b's measured mean-square weight of the
+    same word, sum w_a^2 ~= sum w_a * (sum w_b^2 / sum w_b), unless `w2_a` is given.  Words where b holds fewer than
+    `min_hits` effective hits, (sum w)^2 / sum w^2, are masked out.  Arrays may be block sums (both sums are additive)."""
+    a, b, q = img_a.astype(np.float64), img_b.astype(np.float64), np.asarray(w2_b, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hits = np.where(q > 0, b * b / q, 0.0)
+        qa = np.asarray(w2_a, dtype=np.float64) if w2_a is not None else np.where(b > 0, a * q / b, 0.0)
+    var = np.maximum(qa - a * a / n_a, 0.0) / float(n_a) ** 2 + np.maximum(q - b * b / n_b, 0.0) / float(n_b) ** 2
+    mask = (hits >= min_hits) & (var > 0)
     z = np.zeros_like(a)
-    z[mask] = (a[mask] - b[mask]) / np.sqrt(var[mask])
+    z[mask] = (a[mask] / n_a - b[mask] / n_b) / np.sqrt(var[mask])
     return z, mask
+
+
+def blocks(img: np.ndarray, k: int = 3) -> np.ndarray:
+    """Sum [4, nz, nx] tallies over k x k pixel blocks (ragged edges dropped)."""
+    c, nz, nx = img.shape
+    return img[:, : nz // k * k, : nx // k * k].reshape(c, nz // k, k, nx // k, k).sum(axis=(2, 4))
+
+
+def class_energy_z(img_a, n_a, img_b, w2_b, n_b):
+    """z of the detected energy per history of each scatter class (whole-image sums), measured variances as above;
+    NaN for a class the reference sample holds fewer than 200 effective hits of."""
+    out = []
+    for k in range(img_a.shape[0]):
+        z, m = measured_z(np.array([img_a[k].sum(dtype=np.float64)]), n_a, np.array([img_b[k].sum(dtype=np.float64)]),
+                          np.array([np.asarray(w2_b[k], dtype=np.float64).sum()]), n_b, min_hits=200.0)
+        out.append(float(z[0]) if m[0] else float("nan"))
+    return out

@@ -30,7 +30,20 @@ def _worker(rank, world, port, input_path, nbatch, hpt, out_path):
         first, count = cases.pkg.sharding.shard_range(nbatch, rank, world)
         img, _ = T.track(0, 42, first, count, hpt, ol.MATH_PORTABLE)
         t = torch.from_numpy(img.view(np.int64).copy())
+        sent = cases.pkg.sharding.reduce_image(t.clone(), dst=0)
+        assert sent == t.numel() * 8
+        # narrowed payload (what bench.py sends when the sums fit 32 bits), and the agreed fallback when they do not:
+        # rank 1 alone holds a word >= 2^31, both ranks must still take the same branch
+        t_narrow = t.clone()
+        assert cases.pkg.sharding.reduce_image(t_narrow, dst=0, narrow=True) == t.numel() * 4
+        big = t.clone()
+        big[0] += (2 ** 31 + 5) * rank
+        assert cases.pkg.sharding.reduce_image(big, dst=0, narrow=True) == t.numel() * 8
         cases.pkg.sharding.reduce_image(t, dst=0)
+        if rank == 0:
+            assert torch.equal(t_narrow, t)
+            big[0] -= 2 ** 31 + 5
+            assert torch.equal(big, t)
         hist = torch.tensor([count * hpt], dtype=torch.int64)
         dist.reduce(hist, dst=0, op=dist.ReduceOp.SUM)  # exact global history count for the normalisation (MC-GPU_v1.3.cu:878)
         if rank == 0:
