@@ -1122,21 +1122,39 @@ int mcgpu_set_geometry_arrays(mcgpu_ctx* ctx, const int n[3], const float spacin
     v.density[i] = d;
     if (d > v.density_max[mat - 1]) v.density_max[mat - 1] = d;
   }
-  H.voxels = std::move(v);
-  if (H.cfg.dose_roi[1] > -1)
-    for (int ax = 0; ax < 3; ++ax) H.cfg.dose_roi[2 * ax + 1] = std::min(H.cfg.dose_roi[2 * ax + 1], H.voxels.n[ax] - 1);
-  // the Woodcock majorant and the set of loaded materials depend on the volume (MC-GPU_v1.3.cu:2220-2233,2294-2296)
-  H.mat = MaterialTables();
-  load_material_files(H.cfg.file_materials, H.voxels, H.mat);
-  ctx->table_cache.clear();
+  // Everything that can fail is built beside the live model and swapped in at the end: after an error return the context
+  // is what it was before the call.  The Woodcock majorant and the set of loaded materials depend on the volume
+  // (MC-GPU_v1.3.cu:2220-2233,2294-2296), so the material tables are rebuilt.
+  MaterialTables mat;
+  load_material_files(H.cfg.file_materials, v, mat);
+  int roi[6];
+  for (int k = 0; k < 6; ++k) roi[k] = H.cfg.dose_roi[k];
+  if (roi[1] > -1)
+    for (int ax = 0; ax < 3; ++ax) roi[2 * ax + 1] = std::min(roi[2 * ax + 1], v.n[ax] - 1);
+  std::swap(H.voxels, v);
+  std::swap(H.mat, mat);
+  int roi_old[6];
+  for (int k = 0; k < 6; ++k) { roi_old[k] = H.cfg.dose_roi[k]; H.cfg.dose_roi[k] = roi[k]; }
   if (ctx->has_device) {
     const int dev = ctx->dev.device_id;
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipDeviceSynchronize());
-    ctx->dev.release();
+    DeviceModel old = std::move(ctx->dev);  // stays allocated until the new model is up
     ctx->dev = DeviceModel();
-    upload_model(*ctx, dev);
+    try {
+      upload_model(*ctx, dev);
+    } catch (...) {
+      ctx->dev.release();
+      ctx->dev = std::move(old);
+      std::swap(H.voxels, v);
+      std::swap(H.mat, mat);
+      for (int k = 0; k < 6; ++k) H.cfg.dose_roi[k] = roi_old[k];
+      throw;
+    }
+    for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = old.sched[k];  // the tuned FAST schedule survives a geometry change
+    old.release();  // NB: the dose tallies belong to a geometry and restart from zero with the new one
   }
+  ctx->table_cache.clear();
   return 0;
   ABI_END
 }

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <fcntl.h>
 #include <unistd.h>
 #include <unordered_map>
 #include <vector>
@@ -91,35 +92,41 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
     cur = c.specific_angles[p];
     seq = cur;
   }
-  FILE* fp = fopen(file_name.c_str(), "wb");
-  if (!fp) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " can not be opened!!");
-  static char iobuf[1 << 22];
-  setvbuf(fp, iobuf, _IOFBF, sizeof iobuf);
-  size_t bytes = 0;
+  // No stdio stream and no shared buffer: header, bands and footer are formatted into memory owned by this call and
+  // written at their offsets with pwrite, so concurrent calls (one scan per GPU in one process) cannot interleave.
+  const int fd = open(file_name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " can not be opened!!");
+  struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) close(fd); } } closer{fd};
+  std::string header, footer;
+  auto appendf = [](std::string& to, const char* fmt, auto... args) {
+    char line[1024];
+    const int k = snprintf(line, sizeof line, fmt, args...);
+    to.append(line, (size_t)std::min<int>(std::max(k, 0), (int)sizeof line - 1));
+  };
   const SourcePose& s = m.source[p];
-  bytes += fprintf(fp, "# \n");
-  bytes += fprintf(fp, "#     *****************************************************************************\n");
-  bytes += fprintf(fp, "#     ***   MC CBCT projection engine for AMD MI355X (MC-GPU v1.3 file contract)  ***\n");
-  bytes += fprintf(fp, "#     ***                                                                       ***\n");
-  bytes += fprintf(fp, "#     ***   drop-in for cbctmc.mc: same inputs, same per-projection output files  ***\n");
-  bytes += fprintf(fp, "#     *****************************************************************************\n");
-  bytes += fprintf(fp, "# \n");
-  bytes += fprintf(fp, "#  *** SIMULATION IN THE GPU USING HIP ***\n");
-  bytes += fprintf(fp, "#\n");
-  bytes += fprintf(fp, "#  Image created counting the energy arriving at each pixel: ideal energy integrating detector.\n");
-  bytes += fprintf(fp, "#  Pixel value units: eV/cm^2 per history (energy fluence).\n");
-  bytes += fprintf(fp, "#  CT projection %d of %d: angle from X axis = %lf (mod 360deg), %lf (no mod 360deg) \n", p + 1, c.num_projections,
+  header += "# \n";
+  header += "#     *****************************************************************************\n";
+  header += "#     ***   MC CBCT projection engine for AMD MI355X (MC-GPU v1.3 file contract)  ***\n";
+  header += "#     ***                                                                       ***\n";
+  header += "#     ***   drop-in for cbctmc.mc: same inputs, same per-projection output files  ***\n";
+  header += "#     *****************************************************************************\n";
+  header += "# \n";
+  header += "#  *** SIMULATION IN THE GPU USING HIP ***\n";
+  header += "#\n";
+  header += "#  Image created counting the energy arriving at each pixel: ideal energy integrating detector.\n";
+  header += "#  Pixel value units: eV/cm^2 per history (energy fluence).\n";
+  appendf(header, "#  CT projection %d of %d: angle from X axis = %lf (mod 360deg), %lf (no mod 360deg) \n", p + 1, c.num_projections,
                    (double)cur, (double)seq);
-  bytes += fprintf(fp, "#  Focal spot position = (%.8f,%.8f,%.8f), cone beam direction = (%.8f,%.8f,%.8f)\n", s.pos[0], s.pos[1], s.pos[2],
+  appendf(header, "#  Focal spot position = (%.8f,%.8f,%.8f), cone beam direction = (%.8f,%.8f,%.8f)\n", s.pos[0], s.pos[1], s.pos[2],
                    s.dir[0], s.dir[1], s.dir[2]);
-  bytes += fprintf(fp, c.enable_specific_angles == 0 ? "#  Specific angles enabled: NO\n" : "#  Specific angles enabled: YES\n");
-  bytes += fprintf(fp, "#  Pixel size:  %lf x %lf = %lf cm^2\n", 1.0 / (double)d0.inv_pixel_size_X, 1.0 / (double)d0.inv_pixel_size_Z,
+  header += c.enable_specific_angles == 0 ? "#  Specific angles enabled: NO\n" : "#  Specific angles enabled: YES\n";
+  appendf(header, "#  Pixel size:  %lf x %lf = %lf cm^2\n", 1.0 / (double)d0.inv_pixel_size_X, 1.0 / (double)d0.inv_pixel_size_Z,
                    1.0 / (double)(d0.inv_pixel_size_X * d0.inv_pixel_size_Z));
-  bytes += fprintf(fp, "#  Number of pixels in X and Z:  %d  %d\n", nx, nz);
-  bytes += fprintf(fp, "#  (X rows given first, a blank line separates the different Z values)\n");
-  bytes += fprintf(fp, "# \n");
-  bytes += fprintf(fp, "#  [NON-SCATTERED] [COMPTON] [RAYLEIGH] [MULTIPLE-SCATTING]\n");
-  bytes += fprintf(fp, "# ==========================================================\n");
+  appendf(header, "#  Number of pixels in X and Z:  %d  %d\n", nx, nz);
+  header += "#  (X rows given first, a blank line separates the different Z values)\n";
+  header += "# \n";
+  header += "#  [NON-SCATTERED] [COMPTON] [RAYLEIGH] [MULTIPLE-SCATTING]\n";
+  header += "# ==========================================================\n";
 
   const double SCALE = 1.0 / 100.0f;  // 1/SCALE_eV (MC-GPU_v1.3.cu:2860)
   const double NORM = SCALE * d0.inv_pixel_size_X * d0.inv_pixel_size_Z / ((double)total_histories);
@@ -186,45 +193,61 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
   }
   double energy_integral = 0.0, maximum = -100.0;
   long max_pixel = 0;
+  off_t data_end = 0;
   {
     // the 63 MB of text go to the file in parallel too: every band is written at its own offset (pwrite); a serial fwrite of
     // the bands was 15 of the 20 ms a projection cost
-    fflush(fp);
-    const int fd = fileno(fp);
-    std::vector<off_t> at((size_t)T + 1, (off_t)ftello(fp));
+    std::vector<off_t> at((size_t)T + 1, (off_t)header.size());
     for (int t = 0; t < T; ++t) at[(size_t)t + 1] = at[(size_t)t] + (off_t)chunks[t].size();
-    std::vector<int> bad((size_t)T, 0);
-    auto put = [&](int t) {
+    std::vector<int> bad((size_t)T + 1, 0);
+    auto put_at = [&](const char* data, size_t len, off_t where) {
       size_t done = 0;
-      while (done < chunks[t].size()) {
-        const ssize_t k = pwrite(fd, chunks[t].data() + done, chunks[t].size() - done, at[(size_t)t] + (off_t)done);
-        if (k <= 0) { bad[(size_t)t] = 1; return; }
+      while (done < len) {
+        const ssize_t k = pwrite(fd, data + done, len - done, where + (off_t)done);
+        if (k <= 0) return false;
         done += (size_t)k;
       }
+      return true;
     };
+    auto put = [&](int t) { bad[(size_t)t] = !put_at(chunks[t].data(), chunks[t].size(), at[(size_t)t]); };
     std::vector<std::thread> th;
     for (int t = 1; t < T; ++t) th.emplace_back(put, t);
+    bad[(size_t)T] = !put_at(header.data(), header.size(), 0);
     put(0);
     for (auto& x : th) x.join();
-    for (int t = 0; t < T; ++t)
-      if (bad[(size_t)t]) { fclose(fp); throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!"); }
-    fseeko(fp, at[(size_t)T], SEEK_SET);
+    for (int t = 0; t <= T; ++t)
+      if (bad[(size_t)t]) {
+        for (int u = 0; u < T; ++u) pool.give(chunks[u].mem);
+        throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!");
+      }
+    data_end = at[(size_t)T];
   }
+  size_t bytes = header.size();
   for (int t = 0; t < T; ++t) {
     pool.give(chunks[t].mem);
     bytes += chunks[t].size();
     energy_integral += integral[t];  // NB: summed per band; the footer's %.3lf is insensitive to the order
     if (maxval[t] > maximum) { maximum = maxval[t]; max_pixel = maxpix[t]; }
   }
-  bytes += fprintf(fp, "#   *** Simulation REPORT: ***\n");
-  bytes += fprintf(fp, "#       Fraction of energy detected (over the mean energy of the spectrum): %.3lf%%\n",
+  footer += "#   *** Simulation REPORT: ***\n";
+  appendf(footer, "#       Fraction of energy detected (over the mean energy of the spectrum): %.3lf%%\n",
                    100.0 * SCALE * (energy_integral / (double)total_histories) / (double)m.spectrum.mean_energy);
-  bytes += fprintf(fp, "#       Maximum energy detected in pixel %i: (x,y)=(%i,%i) -> pixel value = %lf eV/cm^2\n", (int)max_pixel,
+  appendf(footer, "#       Maximum energy detected in pixel %i: (x,y)=(%i,%i) -> pixel value = %lf eV/cm^2\n", (int)max_pixel,
                    (int)(max_pixel % nx), (int)(max_pixel / nx), NORM * maximum);
-  bytes += fprintf(fp, "#       Simulated x rays:    %lld\n", (long long)total_histories);
-  bytes += fprintf(fp, "#       Simulation time [s]: %.2f\n", seconds);
-  if (seconds > 0.000001) bytes += fprintf(fp, "#       Speed [x-rays/sec]:  %.2f\n\n", ((double)total_histories) / seconds);
-  if (fclose(fp) != 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!");
+  appendf(footer, "#       Simulated x rays:    %lld\n", (long long)total_histories);
+  appendf(footer, "#       Simulation time [s]: %.2f\n", seconds);
+  if (seconds > 0.000001) appendf(footer, "#       Speed [x-rays/sec]:  %.2f\n\n", ((double)total_histories) / seconds);
+  {
+    size_t done = 0;
+    while (done < footer.size()) {
+      const ssize_t k = pwrite(fd, footer.data() + done, footer.size() - done, data_end + (off_t)done);
+      if (k <= 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!");
+      done += (size_t)k;
+    }
+    bytes += footer.size();
+  }
+  closer.fd = -1;
+  if (close(fd) != 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!");
   return bytes;
 }
 

@@ -218,10 +218,12 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     for (int g = 0; g < n_ctx; ++g) { D[g].lo = units * g / n_ctx; D[g].hi = units * (g + 1) / n_ctx; }
     for (int b = 0; b < 2; ++b) {
       HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));
-      // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte; the event orders the accesses
+      // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte (ordering: see the event below)
       HIP_OK(hipHostMalloc((void**)&planes_host[b], 3 * plane * 4, pinned_flags));
       if (opt->write_ascii) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, pinned_flags));
-      HIP_OK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+      // the writer thread reads non-coherent pinned memory after waiting on this event: that needs a SYSTEM-scope release,
+      // which a default event does not promise (device scope only)
+      HIP_OK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming | hipEventReleaseToSystem));
     }
     const bool shared = opt->shared_stacks != nullptr;  // 4-D: the caller owns stacks that several scans fill by slice index
     if (shared && !opt->slice_of_projection) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: shared_stacks needs slice_of_projection"};

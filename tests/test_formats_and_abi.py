@@ -207,3 +207,38 @@ def test_aluminium_table_with_float_formatted_integer_columns(engine, tmp_path):
         assert np.array_equal(tabs[0][n], tabs[1][n]), n
     itu = tabs[0]["ituco"].reshape(25, 128)[k]
     assert itu[0] == 4 and itu.max() == 128 and tabs[0]["noscco"].view("<i4")[k] == 5
+
+
+def test_ascii_writer_is_safe_under_concurrent_calls(engine, case_dir, tmp_path):
+    """Two threads writing projection files through the public ABI at the same time (e.g. one scan per GPU in one process)
+    give the bytes of the single-threaded writes: no buffer is shared between calls."""
+    import threading
+    with engine.create(case_dir("catphan64_ct"), device=-1) as ctx:
+        rng = np.random.default_rng(3)
+        nz, nx = ctx.detector_shape
+        images = [rng.integers(0, 10**9, size=(4, nz, nx), dtype=np.uint64) for _ in range(4)]
+        want = []
+        for k, img in enumerate(images):
+            f = tmp_path / f"serial_{k}"
+            ctx.write_projection(k, img, 1_000_000 + k, 1.5, file_name=str(f))
+            want.append(f.read_bytes())
+        errors = []
+
+        def worker(t):
+            try:
+                for rep in range(15):
+                    for k, img in enumerate(images):
+                        f = tmp_path / f"thread{t}_{rep}_{k}"
+                        ctx.write_projection(k, img, 1_000_000 + k, 1.5, file_name=str(f))
+                        if f.read_bytes() != want[k]:
+                            errors.append((t, rep, k))
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:5]
+        assert want[0].startswith(b"# \n#     ****") and b"Simulated x rays:    1000000\n" in want[0]
