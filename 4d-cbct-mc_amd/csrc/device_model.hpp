@@ -30,7 +30,6 @@ enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
-constexpr int kQueueRecordsPerBlock = 2048;  // event-queue kernel: history records per 1024-thread workgroup
 constexpr int kSlotWords = 14;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kNumStats = 28;             // scheduler counters of the diagnostic build
 constexpr int kWaveTrace = 16384;         // diagnostic build: {hardware id, first and last clock} of up to this many waves follow the counters
@@ -39,7 +38,7 @@ constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
 // Byte offsets of the kernel's dynamic LDS image (track_common.inc: stage_tables).  Sized for the materials and
 // palette entries actually in use so that three 512-thread workgroups fit one CU's 160 KiB.
 struct LdsLayout {
-  int shells;                // float4 {U, J, f, 0}[sum of shells over the materials], material after material
+  int shells;                // float4 {U, J, f, 0} (COMPAT) / {U, J, alias cut-off, alias shell} (FAST) [sum of shells], material after material
   int nosc;                  // int[2 * nmat]: number of shells, then first shell, per material
   int espc, cutoff, alias;   // float[nbins + 1], float[nbins + 1], short[nbins + 1]
   int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
@@ -49,9 +48,6 @@ struct LdsLayout {
   // FAST kernel only: brackets of the total cross section per (coarse energy bin, material), TrackArgs::sig_shift >= 0
   int sig_mid;               // fp16[ncoarse * nmat]: centre of [min, max] of mfp_tot over the coarse bin
   int sig_w;                 // float[ncoarse]: relative half width that covers every material of the bin
-  // event-queue kernel only (its own layout: `slots` then holds kQueueRecordsPerBlock records)
-  int qctl;                  // u32 head[8], tail[8], exhausted flag
-  int qring;                 // u16[5][kQueueRecordsPerBlock]
   int total;                 // bytes
 };
 
@@ -63,6 +59,8 @@ struct TrackCold {
   const unsigned char *itl, *itu;
   const float *fco, *uico, *fj0;  // [shell*nmat + mc]
   const int* noscco;              // [nmat]
+  const float* shell_cut;         // FAST: Walker alias table of the shell weights f_i per material, [shell*nmat + mc]:
+  const unsigned char* shell_alias;  //   cut-off of column `shell` and the shell its upper part maps to
   // spectrum
   const float *espc, *cutoff;
   const short* alias;

@@ -24,8 +24,6 @@ hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t st
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
 int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
-hipError_t launch_track_queue(const TrackArgs& args, int blocks, hipStream_t stream);
-hipError_t launch_track_pool3(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 hipError_t launch_warp(int nx, int ny, int nz, const unsigned char* mat, const float* dens, const float* dvf, unsigned char default_mat,
@@ -61,10 +59,6 @@ struct DeviceModel {
   int num_spectrum_bins = 0;
   int shell_first[kMaxMaterials] = {0};
   LdsLayout lds;
-  LdsLayout lds_pool3;      // three histories per lane: two slot planes (total 0 = does not fit)
-  int sig_shift_pool3 = -1;
-  LdsLayout lds_queue;      // layout of the event-queue kernel (total 0 = does not fit: use the lane-bound kernel)
-  int sig_shift_queue = -1;
   TrackCold* cold = nullptr;      // device copy of the rarely used table pointers
   TrackCold cold_host;            // its host image (re-uploaded when a tuning knob changes)
   unsigned long long* dose_voxels = nullptr;     // ulonglong2 per ROI voxel (null: tally off)
@@ -87,6 +81,8 @@ struct DeviceModel {
   unsigned char *itl = nullptr, *itu = nullptr;
   float *fco = nullptr, *uico = nullptr, *fj0 = nullptr;
   int* noscco = nullptr;
+  float* shell_cut = nullptr;      // FAST: alias table of the Compton shell weights
+  unsigned char* shell_alias = nullptr;
   float *espc = nullptr, *cutoff = nullptr;
   short* alias = nullptr;
   int nmat = 0;
@@ -314,23 +310,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       const Float3& b = H.mat.b[(size_t)i * kMaxMaterials + m];
       r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
       r[6] = H.mat.pmax[(size_t)(i + 1) * kMaxMaterials + m];
-      {
-        // FAST Compton sampler (track_common.inc: compton_angle_trial): upper bound of s0 = S(E, theta = pi) =
-        // sum_i f_i n_i(E, cdt = 2) (K.cu:1299-1314) over this energy bin.  Every n_i grows with E and shells only switch
-        // on, so the value at the bin's upper edge bounds the bin; the margin covers float rounding on the device.
-        const double E = (double)H.mat.e0 + (double)(i + 1) / (double)H.mat.ide, mc2 = 510998.918;
-        double s0 = 0.0;
-        for (int k = 0; k < std::min(H.mat.noscco[m], kMaxShells); ++k) {
-          const double U = H.mat.uico[m + k * kMaxMaterials], J = H.mat.fj0[m + k * kMaxMaterials], f = H.mat.fco[m + k * kMaxMaterials];
-          if (!(U < E)) continue;
-          const double aux = E * (E - U) * 2.0;
-          const double pz = J * (aux - U * mc2) / (std::sqrt(aux + aux + U * U) * mc2);
-          const double q = 0.70710678118654502 + std::fabs(pz) * 1.4142135623731;
-          const double n = 0.5 * std::exp(0.5 - q * q);
-          s0 += f * (pz > 0.0 ? 1.0 - n : n);
-        }
-        r[7] = (float)(s0 * 1.0001);
-      }
+      r[7] = 0.f;
     }
   D.woodcock = D.put(wood);
   D.mfp = D.put(rec);
@@ -349,6 +329,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
   std::vector<unsigned char> itl(kRayleighPoints * nmat), itu(itl);
   std::vector<float> fco(kMaxShells * nmat, 0.f), uico(fco), fj0(fco);
   std::vector<int> nosc(std::max(nmat, 1), 0);
+  std::vector<float> shell_cut(kMaxShells * std::max(nmat, 1), 1.0f);
+  std::vector<unsigned char> shell_alias(kMaxShells * std::max(nmat, 1), 0);
   for (int m = 0; m < kMaxMaterials; ++m) {
     const int mc = D.compact_of[m];
     if (mc < 0) continue;
@@ -366,11 +348,36 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       fj0[s * nmat + mc] = H.mat.fj0[m + s * kMaxMaterials];
     }
     nosc[mc] = H.mat.noscco[m];
+    {
+      // FAST Compton sampler (track_common.inc: compton_draw): Walker alias table of the shell weights f_i (Vose's
+      // construction, in double): column k keeps shell k below cut[k] and maps the rest of the column to alias[k]
+      const int n = std::min(H.mat.noscco[m], kMaxShells);
+      double F = 0.0;
+      for (int s = 0; s < n; ++s) F += (double)H.mat.fco[m + s * kMaxMaterials];
+      std::vector<double> q(n);
+      std::vector<int> small, large;
+      for (int s = 0; s < n; ++s) {
+        q[s] = F > 0.0 ? (double)H.mat.fco[m + s * kMaxMaterials] * n / F : 1.0;
+        (q[s] < 1.0 ? small : large).push_back(s);
+        shell_cut[s * nmat + mc] = 1.0f;
+        shell_alias[s * nmat + mc] = (unsigned char)s;
+      }
+      while (!small.empty() && !large.empty()) {
+        const int a = small.back(), b = large.back();
+        small.pop_back();
+        shell_cut[a * nmat + mc] = (float)q[a];
+        shell_alias[a * nmat + mc] = (unsigned char)b;
+        q[b] -= 1.0 - q[a];
+        if (q[b] < 1.0) { large.pop_back(); small.push_back(b); }
+      }
+    }
   }
   D.xco = D.put(xco); D.pco = D.put(pco); D.aco = D.put(aco); D.bco = D.put(bco);
   D.itl = D.put(itl); D.itu = D.put(itu);
   D.fco = D.put(fco); D.uico = D.put(uico); D.fj0 = D.put(fj0);
   D.noscco = D.put(nosc);
+  D.shell_cut = D.put(shell_cut);
+  D.shell_alias = D.put(shell_alias);
   D.espc = D.put(std::vector<float>(H.spectrum.espc, H.spectrum.espc + kMaxSpectrumBins));
   D.cutoff = D.put(std::vector<float>(H.spectrum.cutoff, H.spectrum.cutoff + kMaxSpectrumBins));
   D.alias = D.put(std::vector<short>(H.spectrum.alias, H.spectrum.alias + kMaxSpectrumBins));
@@ -409,37 +416,6 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       }
     }
     Y.total = (off + 15) / 16 * 16;
-    // event-queue kernel: same tables, then kQueueRecordsPerBlock records, the brackets, queue counters and rings
-    LdsLayout Q = Y;
-    int qoff = Y.slots;
-    auto qtake = [&](int bytes, int align) { qoff = (qoff + align - 1) / align * align; const int at = qoff; qoff += bytes; return at; };
-    qtake(kSlotWords * kQueueRecordsPerBlock * 4, 16);
-    Q.qctl = qtake(32 * 4, 16);
-    Q.qring = qtake(5 * kQueueRecordsPerBlock * 2, 16);
-    Q.sig_mid = Q.sig_w = qoff;
-    D.sig_shift_queue = -1;
-    if (D.sig_shift >= 0) {  // the same table as the lane-bound kernel, if it fits here too
-      const int nc = D.sig_coarse;
-      const int need = (qoff + 15) / 16 * 16 + (nc * nmat * 2 + 15) / 16 * 16 + (nc * 4 + 15) / 16 * 16;
-      if (need <= 160 * 1024) { Q.sig_mid = qtake(nc * nmat * 2, 16); Q.sig_w = qtake(nc * 4, 16); D.sig_shift_queue = D.sig_shift; }
-    }
-    Q.total = (qoff + 15) / 16 * 16;
-    if (Q.total > 160 * 1024) Q.total = 0;
-    D.lds_queue = Q;
-    // three histories per lane: two slot planes behind the tables, then the brackets
-    LdsLayout P3 = Y;
-    int poff = Y.slots + 2 * kSlotWords * kPoolBlockThreads * 4;
-    P3.sig_mid = P3.sig_w = poff;
-    D.sig_shift_pool3 = -1;
-    if (D.sig_shift >= 0) {
-      const int nc = D.sig_coarse;
-      P3.sig_mid = (poff + 15) / 16 * 16; poff = P3.sig_mid + nc * nmat * 2;
-      P3.sig_w = (poff + 15) / 16 * 16; poff = P3.sig_w + nc * 4;
-      D.sig_shift_pool3 = D.sig_shift;
-    }
-    P3.total = (poff + 15) / 16 * 16;
-    if (P3.total > 160 * 1024) P3.total = 0;
-    D.lds_pool3 = P3;
   }
   if (D.sig_shift >= 0) {
     const int nc = D.sig_coarse, shift = D.sig_shift;
@@ -487,6 +463,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     memset(&cold, 0, sizeof cold);
     cold.xco = D.xco; cold.pco = D.pco; cold.aco = D.aco; cold.bco = D.bco; cold.itl = D.itl; cold.itu = D.itu;
     cold.fco = D.fco; cold.uico = D.uico; cold.fj0 = D.fj0; cold.noscco = D.noscco;
+    cold.shell_cut = D.shell_cut; cold.shell_alias = D.shell_alias;
     cold.espc = D.espc; cold.cutoff = D.cutoff; cold.alias = D.alias;
     cold.bricks = D.bricks;
     cold.sig_mid = D.sig_mid; cold.sig_w = D.sig_w;
@@ -810,23 +787,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         A.stats = D.stats;
         HIP_TRY(launch_track_stats(A, (int)std::min(want, resident), stream));
       } else {
-        // MCGPU_FAST_KERNEL=queue: the event-queue organisation (track_pool.inc), one workgroup per CU
-        const char* fk = getenv("MCGPU_FAST_KERNEL");
-        if (fk && !strcmp(fk, "queue") && D.lds_queue.total > 0) {
-          A.lds = D.lds_queue;
-          A.sig_shift = D.sig_shift_queue;
-          if (getenv("MCGPU_QUEUE_STATS")) {  // diagnostics: counters of the queue kernel in the scheduler-stats buffer
-            if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats + 3 * kWaveTrace, 0ULL));
-            A.stats = D.stats;
-          }
-          HIP_TRY(launch_track_queue(A, (int)std::min<unsigned long long>(want, (unsigned long long)D.num_cus), stream));
-        } else if (fk && !strcmp(fk, "pool3") && D.lds_pool3.total > 0) {
-          A.lds = D.lds_pool3;
-          A.sig_shift = D.sig_shift_pool3;
-          HIP_TRY(launch_track_pool3(A, (int)std::min<unsigned long long>(want, (unsigned long long)D.num_cus), stream));
-        } else {
-          HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
-        }
+        HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
       }
     }
   }

@@ -168,19 +168,6 @@ def test_fast_cross_section_brackets_decide_like_the_exact_table(gpu_engine, cas
         assert imgs[(case, False)].sum() > 0
 
 
-def test_fast_event_queue_kernel_equals_lane_bound_kernel(gpu_engine, case_dir, monkeypatch):
-    """MCGPU_FAST_KERNEL=queue runs the same per-history arithmetic from workgroup-level queues (track_pool.inc:
-    track_queue_kernel): the tally must be identical word for word, including the dose tallies."""
-    for case, n in (("catphan64_ct", 600_000), ("water", 100_000), ("catphan64_dose", 300_000)):
-        with gpu_engine.create(case_dir(case), device=0) as ctx:
-            ref = ctx.run_projection(0, n, mode="fast", seed=9)[0]
-            monkeypatch.setenv("MCGPU_FAST_KERNEL", "queue")
-            for rep in range(2):
-                img = ctx.run_projection(0, n, mode="fast", seed=9)[0]
-                assert np.array_equal(img, ref), (case, rep)
-            monkeypatch.delenv("MCGPU_FAST_KERNEL")
-
-
 def test_fast_exterior_hop_is_statistically_equivalent_to_delta_tracking(gpu_engine, case_dir, monkeypatch):
     """The analytic crossing of the homogeneous exterior (track_pool.inc: exterior_hop) against plain Woodcock tracking
     everywhere (MCGPU_NO_EXTERIOR): two independent estimates of the same images."""
