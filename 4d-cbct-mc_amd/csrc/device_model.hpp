@@ -30,8 +30,9 @@ enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
+constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)
 constexpr int kSlotWords = 14;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
-constexpr int kNumStats = 28;             // scheduler counters of the diagnostic build
+constexpr int kNumStats = 32;             // scheduler counters of the diagnostic build
 constexpr int kWaveTrace = 16384;         // diagnostic build: {hardware id, first and last clock} of up to this many waves follow the counters
 constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
 
@@ -79,6 +80,7 @@ struct TrackCold {
   // parked histories per wave64 that trigger a batched service of that kind; service everything well populated when
   // fewer lanes than `flyable_low` can fly; stop for a scheduling point once `swap_batch` more lanes have parked
   int thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch;
+  int trade_slots;  // 1: lanes of a wave trade their parking slots at scheduling points (0: MCGPU_NO_SLOT_TRADE, for A/B runs)
 };
 
 struct TrackArgs {
@@ -118,7 +120,7 @@ struct TrackArgs {
   int thresh_compton, thresh_rayleigh, thresh_new;
   int dose_flags;             // bit 0: material dose tally, bit 1: voxel dose tally (TrackCold holds the buffers)
   unsigned long long* stats;  // diagnostic build only (kNumStats counters), else null
-  unsigned long long* work_counter;  // FAST: next unassigned history offset (zeroed before each launch)
+  unsigned long long* work_counter;  // FAST: kNumCounters id dispensers, kCounterStride words apart (zeroed before each launch)
 };
 
 }  // namespace mcgpu

@@ -487,7 +487,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
     for (int m = 0; m < kMaxMaterials; ++m) cold.shell_first[m] = D.shell_first[m];
     for (int k = 0; k < 3; ++k) { cold.objbox_lo[k] = D.objbox_lo[k]; cold.objbox_hi[k] = D.objbox_hi[k]; }
-    cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = -1;  // set at launch
+    cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = cold.trade_slots = -1;  // set at launch
     D.cold_host = cold;
     D.cold = D.put(std::vector<TrackCold>(1, cold));
     D.src_all = D.put(H.source);
@@ -532,6 +532,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? env_int("MCGPU_EXTERIOR_MODE", 3) : 0;  // bit 0: hop during flight, bit 1: hop at the source
+  if (getenv("MCGPU_DEBUG_NO_TALLY")) A.has_exterior |= 4 * atoi(getenv("MCGPU_DEBUG_NO_TALLY"));  // 1: none, 2: plain store, 4: 32-bit atomic  // experiment: FAST kernel without its detector atomics (wrong images)
   // batching thresholds of the COMPAT kernel (one history per lane)
   A.thresh_compton = env_int("MCGPU_COMPAT_THRESH_COMPTON", 20);
   A.thresh_rayleigh = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", 6);
@@ -772,15 +773,17 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         TrackCold& ch = D.cold_host;
         const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", D.sched[0]), env_int("MCGPU_THRESH_RAYLEIGH", D.sched[1]), env_int("MCGPU_THRESH_NEW", D.sched[2]),
                               std::max(1, env_int("MCGPU_FLYABLE_LOW", D.sched[3])), std::max(1, env_int("MCGPU_SWAP_BATCH", D.sched[4]))};
-        if (ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
+        const int trade = getenv("MCGPU_NO_SLOT_TRADE") ? 0 : 1;
+        if (ch.trade_slots != trade || ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
             ch.swap_batch != want5[4]) {
           ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];
+          ch.trade_slots = trade;
           HIP_TRY(hipStreamSynchronize(stream));
           HIP_TRY(hipMemcpy(D.cold, &ch, sizeof ch, hipMemcpyHostToDevice));
         }
       }
-      if (!D.work_counter) D.work_counter = D.put(std::vector<unsigned long long>(2, 0ULL));
-      HIP_TRY(hipMemsetAsync(D.work_counter, 0, 8, stream));
+      if (!D.work_counter) D.work_counter = D.put(std::vector<unsigned long long>((size_t)kNumCounters * kCounterStride, 0ULL));
+      HIP_TRY(hipMemsetAsync(D.work_counter, 0, (size_t)kNumCounters * kCounterStride * 8, stream));
       A.work_counter = D.work_counter;
       if (mode == MCGPU_MODE_FAST_STATS) {
         if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats + 3 * kWaveTrace, 0ULL));

@@ -64,7 +64,7 @@ def load_library(path: Optional[os.PathLike] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("MCGPU_ENGINE_LIB") or LIB_PATH)  # the override: A/B runs of two builds on one GPU box
     if not p.exists():
         raise ImportError(f"{p} not found: build the HIP engine first (python __graft_entry__.py or make -C 4d-cbct-mc_amd/csrc)")
     lib = C.CDLL(str(p))
@@ -280,12 +280,13 @@ class Context:
 
     def scheduler_stats(self, reset: bool = True) -> dict:
         """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""
-        out = (C.c_ulonglong * 28)()
-        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 28, int(reset)))
+        out = (C.c_ulonglong * 32)()
+        _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 32, int(reset)))
         names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
                  "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight",
-                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "lanes_idle", "lanes_both_flyable",
-                 "iter_with_voxel_load", "voxel_load_lanes", "iter_with_sigma_load", "sigma_load_lanes")
+                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "slots_traded", "lanes_both_flyable",
+                 "iter_with_voxel_load", "voxel_load_lanes", "iter_with_sigma_load", "sigma_load_lanes",
+                 "cycles_flight_to_voxel", "cycles_flight_resolve", "cycles_settle", "cycles_sched_point")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

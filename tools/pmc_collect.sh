@@ -6,7 +6,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end}
+ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat}
 i=0
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY" \
@@ -16,5 +16,6 @@ for set in \
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 bench.py $ARGS > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || echo "pass $i failed"
 done
-python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.json"
+WL=catphan; case "$ARGS" in *"--workload cirs"*) WL=cirs;; *"--workload thorax"*) WL=thorax;; esac
+python3 tools/pmc_summary.py "$OUT" $WL > "$OUT/summary.json"
 cat "$OUT/summary.json"

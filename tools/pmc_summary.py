@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 counter_collection CSVs: mean value per track_kernel dispatch, per counter."""
-import csv, glob, json, sys
+"""Summarise rocprofv3 counter_collection CSVs: mean value per track_pool_kernel dispatch, per counter, stamped with the
+kernel build (hash of the FAST kernel's sources, bench.kernel_source_hash) and the workload, so that bench.py can refuse a
+summary that belongs to another build.  Usage: pmc_summary.py <dir with pass*/> [workload]"""
+import csv, glob, json, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import bench
 out = {}
 for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=True):
     acc = {}
@@ -12,4 +17,6 @@ for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=
     for name, d in acc.items():
         v = list(d.values())
         out[name] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v)}
+out["_stamp"] = {"kernel_source_sha16": bench.kernel_source_hash(), "workload": sys.argv[2] if len(sys.argv) > 2 else "catphan",
+                 "histories_per_dispatch": 100000000, "collected": time.strftime("%Y-%m-%d %H:%M:%S")}
 print(json.dumps(out, indent=1))
