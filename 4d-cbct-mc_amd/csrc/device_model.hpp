@@ -11,6 +11,8 @@
 //               14 = EXTERIOR (background brick outside the bounding box of everything else), else 0xF ("mixed":
 //               read the voxel).  Most Woodcock steps land in homogeneous bricks (air, water
 //               body) and never touch the volume.
+//   sub       : the same 4-bit codes per sub-brick of 4^3 voxels, dense over the volume (0.5 MB for 512x512x256), L2-resident:
+//               asked by a flight step that lands in a mixed brick before it asks the volume (FAST kernel)
 //   mfp_tot   : per (energy bin, compact material) float2 {a_tot, b_tot}: 1.9 MB, L2-resident; the FAST flight step reads
 //               only this (virtual-or-real test); the kind of a real interaction is drawn later, in a batch
 //   mfp       : per (energy bin, compact material) one 32-byte record
@@ -89,6 +91,8 @@ struct TrackArgs {
   const float* palette;  // float2 pairs {density, bits(mat_c)}
   int vol_kind, palette_size;
   int brick_shift, brick_nx, brick_nxy, brick_bytes;
+  const unsigned char* sub;  // FAST: second-level codes, 4 bits per 4^3-voxel sub-brick, dense (null: none)
+  int sub_nx, sub_nxy;
   float brick_scale[3];  // inv_vs / 2^brick_shift: position -> brick coordinate
   int nx, ny, nz, nxy;
   float inv_vs[3];

@@ -52,6 +52,8 @@ struct DeviceModel {
   int vol_kind = kVolU8, palette_size = 0;
   float* palette = nullptr;
   unsigned char* bricks = nullptr;
+  unsigned char* sub = nullptr;   // second-level codes: 4 bits per sub-brick of 4^3 voxels, dense over the volume (u8 volumes)
+  int sub_n[3] = {1, 1, 1}, sub_mixed = 0;
   int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, brick_bytes = 0, bricks_mixed = 0;
   int brick_palette[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int has_exterior = 0, bricks_exterior = 0;
@@ -218,14 +220,22 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     D.brick_count = D.brick_n[0] * D.brick_n[1] * D.brick_n[2];
     std::vector<int> first(D.brick_count, -1);
     std::vector<unsigned char> mixed(D.brick_count, 0);
+    // second level: sub-bricks of 4^3 voxels, dense over the volume (first2: palette entry, 0x100 = mixed)
+    D.sub_n[0] = (nx + 3) >> 2; D.sub_n[1] = (ny + 3) >> 2; D.sub_n[2] = (nz + 3) >> 2;
+    const size_t nsub = (size_t)D.sub_n[0] * D.sub_n[1] * D.sub_n[2];
+    std::vector<short> first2(nsub, -1);
     for (int z = 0; z < nz; ++z)
       for (int y = 0; y < ny; ++y) {
         const size_t row = ((size_t)z * ny + y) * nx;
         const size_t brow = ((size_t)(z >> k) * D.brick_n[1] + (y >> k)) * D.brick_n[0];
+        const size_t srow = ((size_t)(z >> 2) * D.sub_n[1] + (y >> 2)) * D.sub_n[0];
         for (int x = 0; x < nx; ++x) {
           const int b = (int)(brow + (x >> k)), v = idx8[row + x];
           if (first[b] < 0) first[b] = v;
           else if (first[b] != v) mixed[b] = 1;
+          short& f2 = first2[srow + (x >> 2)];
+          if (f2 < 0) f2 = (short)v;
+          else if (f2 != v) f2 = 0x100;
         }
       }
     // 4-bit codes: the 14 most frequent palette entries among homogeneous bricks get codes 0..13, every other
@@ -290,6 +300,27 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       bricks[b >> 1] = (unsigned char)((bricks[b >> 1] & ~(0xF << sh)) | (code << sh));
     }
     D.bricks = D.put(bricks);
+    {
+      // Second-level codes (same 4-bit coding, no EXTERIOR): a flight step that lands in a mixed brick asks this table,
+      // which stays in L2 (0.5-1 MB), before it asks the volume (64-128 MiB: Infinity Cache / HBM).  On a body-filling
+      // volume 78 % of the tissue voxels lie in mixed 16^3 bricks but only 24 % in mixed 4^3 sub-bricks, and the voxel
+      // gathers of the flight step were what bound that workload (1.45 KB of fabric traffic per history at 5e9 histories/s).
+      std::vector<unsigned char> sub((nsub + 1) / 2, 0xFF);
+      D.sub_mixed = 0;
+      // Worth its dependent L2 round trip only where most bricks a photon meets are mixed (body-filling volumes: 61 % of
+      // the bricks inside the object box of the thorax workload, +24 %; Catphan 43 %: -1.5 %, CIRS with its 8^3 bricks 28 %:
+      // -7 %); MCGPU_SUB_BRICKS=0/1 overrides.
+      const long inside = (long)D.brick_count - D.bricks_exterior;
+      const char* knob = getenv("MCGPU_SUB_BRICKS");
+      const bool off = knob ? atoi(knob) == 0 : !(inside > 0 && 2L * D.bricks_mixed > inside);
+      for (size_t b = 0; b < nsub; ++b) {
+        const int code = (!off && first2[b] >= 0 && first2[b] < 0x100) ? code_of[first2[b]] : 0xF;
+        D.sub_mixed += (code == 0xF);
+        const int sh = (int)(b & 1) * 4;
+        sub[b >> 1] = (unsigned char)((sub[b >> 1] & ~(0xF << sh)) | (code << sh));
+      }
+      D.sub = off ? nullptr : D.put(sub);
+    }
   } else {
     D.vol_kind = kVolU16;
     D.vol = D.put(idx16);
@@ -508,6 +539,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.vol = D.vol; A.palette = D.palette; A.vol_kind = D.vol_kind; A.palette_size = D.palette_size;
   A.brick_shift = D.brick_shift; A.brick_nx = D.brick_n[0]; A.brick_nxy = D.brick_n[0] * D.brick_n[1];
   A.brick_bytes = D.vol_kind == kVolU8 ? D.brick_bytes : 0;
+  A.sub = D.vol_kind == kVolU8 ? D.sub : nullptr; A.sub_nx = D.sub_n[0]; A.sub_nxy = D.sub_n[0] * D.sub_n[1];
   A.lds = D.lds;
   A.nx = H.voxels.n[0]; A.ny = H.voxels.n[1]; A.nz = H.voxels.n[2]; A.nxy = A.nx * A.ny;
   for (int k = 0; k < 3; ++k) {
@@ -658,6 +690,8 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "brick_count") *value = ctx->dev.brick_count;
   else if (k == "bricks_mixed") *value = ctx->dev.bricks_mixed;
   else if (k == "bricks_exterior") *value = ctx->dev.bricks_exterior;
+  else if (k == "sub_bricks") *value = (long long)ctx->dev.sub_n[0] * ctx->dev.sub_n[1] * ctx->dev.sub_n[2];
+  else if (k == "sub_bricks_mixed") *value = ctx->dev.sub_mixed;
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
   else if (k == "sigma_bracket_shift") *value = ctx->dev.sig_shift;

@@ -35,10 +35,4 @@ def engine():
     import cases
     eng = cases.pkg.engine
     eng.load_library()
-    try:  # tests that hand torch tensors to the engine: bring torch's HIP context up before the engine's first context
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:  # noqa: BLE001 -- no torch / no GPU: the CPU suite does not need it
-        pass
     return eng
