@@ -77,7 +77,7 @@ struct DeviceModel {
   unsigned short* sig_mid = nullptr;  // cross-section brackets (FAST flight step), see upload_model
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
-  int sched[5] = {24, 8, 36, 12, 24};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
+  int sched[5] = {32, 8, 36, 12, 32};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;

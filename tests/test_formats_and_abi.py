@@ -242,3 +242,18 @@ def test_ascii_writer_is_safe_under_concurrent_calls(engine, case_dir, tmp_path)
             t.join()
         assert not errors, errors[:5]
         assert want[0].startswith(b"# \n#     ****") and b"Simulated x rays:    1000000\n" in want[0]
+
+
+def test_mpirun_shim_translates_the_reference_command_line(tmp_path):
+    """docker/mpirun is what `mpirun --tag-output -v -n <N> MC-GPU_v1.3.x <input>` (cbctmc/mc/simulation.py:187-198) resolves to
+    inside the ROCm image: it must hand the executable its input file and the rank count as `--gpus N`."""
+    import subprocess
+    shim = ROOT / "docker" / "mpirun"
+    probe = tmp_path / "probe.sh"
+    probe.write_text('#!/bin/sh\nfor a in "$@"; do printf "[%s]" "$a"; done; echo\n')
+    probe.chmod(0o755)
+    run = lambda *argv: subprocess.run(["sh", str(shim), *argv], capture_output=True, text=True, check=True).stdout.strip()
+    assert run("--tag-output", "-v", "-n", "2", str(probe), "/host/run/input.in") == "[/host/run/input.in][--gpus][2]"
+    assert run("-np", "8", str(probe), "a b.in") == "[a b.in][--gpus][8]"       # spaces survive
+    assert run(str(probe), "input.in") == "[input.in][--gpus][1]"                # no -n: one rank
+    assert run("--tag-output", "-v", "-n", "4", "/bin/echo", "in") == "in --gpus 4"

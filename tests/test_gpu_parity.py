@@ -224,3 +224,23 @@ def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, cas
     for k in range(4):  # detected energy per history per class
         zk = (b[k].sum() - mean[k].sum()) / np.sqrt(var_ref[k].sum() * 2.0)
         assert abs(zk) < 4.5, (k, zk)
+
+
+def test_fast_kernel_tallies_are_pinned(gpu_engine):
+    """The production kernel is built without implicit FMA contraction, so its integer tallies are a function of the source
+    alone: tests/golden/fast_pin.json (written on an MI355X by tools/gen_fast_pin.py) holds their SHA-256 on four small cases.
+    A mismatch means the FAST arithmetic or its random-number use changed -- regenerate the pin only if that was intended
+    (the statistical tests above are what shows a change is still correct)."""
+    import json
+    import sys
+    sys.path.insert(0, str(cases_root() / "tools"))
+    import gen_fast_pin
+    want = json.loads((cases_root() / "tests" / "golden" / "fast_pin.json").read_text())
+    got = gen_fast_pin.compute()
+    for name in want:
+        assert got[name]["sum"] == want[name]["sum"] and got[name]["sha256"] == want[name]["sha256"], name
+
+
+def cases_root():
+    from pathlib import Path
+    return Path(__file__).resolve().parents[1]
