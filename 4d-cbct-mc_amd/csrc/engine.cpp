@@ -17,6 +17,7 @@
 
 #include "../../include/mcgpu_amd.h"
 #include "device_model.hpp"
+#include "geometry_device.hpp"
 
 namespace mcgpu {
 
@@ -52,6 +53,16 @@ struct DeviceModel {
   int vol_kind = kVolU8, palette_size = 0;
   float* palette = nullptr;
   unsigned char* bricks = nullptr;
+  // on-device geometry changes (mcgpu_warp_geometry): the base geometry's palette index volume, scratch, the palette on the
+  // host and the code assignment of the base geometry
+  unsigned char* vol_base = nullptr;
+  unsigned short *sub_first = nullptr, *brick_first = nullptr;
+  unsigned char* code_of_dev = nullptr;
+  unsigned int* rebuild_out = nullptr;
+  float* dvf = nullptr;
+  std::vector<float> palette_host;  // {density, bits(compact material)} pairs
+  unsigned char code_of[256];
+  int background = 0;
   unsigned char* sub = nullptr;   // second-level codes: 4 bits per sub-brick of 4^3 voxels, dense over the volume (u8 volumes)
   int sub_n[3] = {1, 1, 1}, sub_mixed = 0;
   int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, brick_bytes = 0, bricks_mixed = 0;
@@ -119,6 +130,7 @@ struct mcgpu_ctx {
   mcgpu::HostModel host;
   mcgpu::DeviceModel dev;
   bool has_device = false;
+  bool host_voxels_stale = false;  // the device holds a geometry warped there (mcgpu_warp_geometry): H.voxels is downloaded on demand
   std::map<std::string, std::vector<unsigned char>> table_cache;
 };
 
@@ -188,6 +200,24 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     D.palette = D.put(std::vector<float>(2, 0.f));
   } else if (index_of.size() <= 256) {
     D.vol_kind = kVolU8;
+    {
+      // the reference's default for voxels warped in from outside the volume (air: material 1 at 0.0013 g/cm^3,
+      // cbctmc/mc/geometry.py:403-418) gets a palette entry even when no voxel holds it yet, so that a geometry can be
+      // warped on the device without touching the palette (mcgpu_warp_geometry)
+      const float air = 0.0013f;
+      uint32_t db;
+      memcpy(&db, &air, 4);
+      const uint64_t key = ((uint64_t)1 << 32) | db;
+      if (!index_of.count(key) && index_of.size() < 256 && D.compact_of[0] >= 0) {
+        const int mc = D.compact_of[0];
+        float mcf;
+        memcpy(&mcf, &mc, 4);
+        index_of.emplace(key, (int)index_of.size());
+        palette.push_back(air);
+        palette.push_back(mcf);
+      }
+    }
+    D.palette_host = palette;
     std::vector<uint8_t> idx8(nvox);
     for (size_t i = 0; i < nvox; ++i) idx8[i] = (uint8_t)idx16[i];
     D.vol = D.put(idx8);
@@ -253,6 +283,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       if (homogeneous[order[c]] > 0) { code_of[order[c]] = c; D.brick_palette[c] = order[c]; }
     }
     D.brick_palette[14] = D.brick_palette[15] = 0;
+    for (int i = 0; i < 256; ++i) D.code_of[i] = (unsigned char)code_of[i];
+    D.background = order[0];
     // Exterior: the object box is the bounding box (in bricks) of every brick that is not homogeneous background
     // (background = the most frequent homogeneous entry).  Bricks outside it are all background: the FAST kernel crosses
     // that region with one exact free-path sample instead of delta-tracking through it (track_pool.inc: exterior_hop).
@@ -573,8 +605,33 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
 }
 
 
+// After mcgpu_warp_geometry the voxels exist on the device only; whoever needs them on the host calls this first.
+void sync_host_voxels(mcgpu_ctx& C) {
+  if (!C.host_voxels_stale) return;
+  HostModel& H = C.host;
+  DeviceModel& D = C.dev;
+  HIP_TRY(hipSetDevice(D.device_id));
+  const size_t nvox = H.voxels.count();
+  std::vector<unsigned char> idx(nvox);
+  HIP_TRY(hipMemcpy(idx.data(), D.vol, nvox, hipMemcpyDeviceToHost));
+  int mat_of[256];
+  float dens_of[256];
+  for (int e = 0; e < D.palette_size; ++e) {
+    int mc;
+    memcpy(&mc, &D.palette_host[2 * e + 1], 4);
+    int number = 1;
+    for (int m = 0; m < kMaxMaterials; ++m)
+      if (D.compact_of[m] == mc) number = m + 1;
+    mat_of[e] = number;
+    dens_of[e] = D.palette_host[2 * e];
+  }
+  for (size_t i = 0; i < nvox; ++i) { H.voxels.material[i] = (uint8_t)mat_of[idx[i]]; H.voxels.density[i] = dens_of[idx[i]]; }
+  C.host_voxels_stale = false;
+}
+
 const void* host_table(mcgpu_ctx& C, const std::string& name, size_t& bytes) {
   HostModel& H = C.host;
+  if (name == "voxel_mat_dens") sync_host_voxels(C);
   auto cache = [&](const void* p, size_t n) -> const void* {
     auto& v = C.table_cache[name];
     v.assign((const unsigned char*)p, (const unsigned char*)p + n);
@@ -642,6 +699,21 @@ int mcgpu_create(const char* input_path, int device_id, mcgpu_ctx** out) {
   require(input_path && out, -1, "!!ERROR!! mcgpu_create: null argument");
   std::unique_ptr<mcgpu_ctx> c(new mcgpu_ctx);
   load_model(input_path, c->host);
+  if (device_id >= 0) {
+    upload_model(*c, device_id);
+    c->has_device = true;
+  }
+  *out = c.release();
+  return 0;
+  ABI_END
+}
+
+int mcgpu_clone(const mcgpu_ctx* src, int device_id, mcgpu_ctx** out) {
+  ABI_BEGIN
+  require(src && out, -1, "!!ERROR!! mcgpu_clone: null argument");
+  std::unique_ptr<mcgpu_ctx> c(new mcgpu_ctx);
+  sync_host_voxels(*const_cast<mcgpu_ctx*>(src));
+  c->host = src->host;
   if (device_id >= 0) {
     upload_model(*c, device_id);
     c->has_device = true;
@@ -964,6 +1036,7 @@ int mcgpu_write_dose_report(mcgpu_ctx* ctx, const uint64_t* voxels, const uint64
                             double seconds, char* log, size_t log_bytes) {
   ABI_BEGIN
   require(ctx != nullptr && histories_per_projection > 0, -1, "!!ERROR!! mcgpu_write_dose_report: bad argument");
+  sync_host_voxels(*ctx);  // voxel densities and material masses come from the host copy
   std::string text;
   if (voxels) {
     require(ctx->host.cfg.dose_roi[1] > -1, -2, "!!ERROR!! mcgpu_write_dose_report: the voxel dose tally is disabled in the input file");
@@ -1152,6 +1225,87 @@ int mcgpu_set_geometry_arrays(mcgpu_ctx* ctx, const int n[3], const float spacin
     for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = old.sched[k];  // the tuned FAST schedule survives a geometry change
     old.release();  // NB: the dose tallies belong to a geometry and restart from zero with the new one
   }
+  ctx->host_voxels_stale = false;
+  ctx->table_cache.clear();
+  return 0;
+  ABI_END
+}
+
+int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, int default_material, float default_density) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && displacement && (frame == 0 || frame == 1), -1, "!!ERROR!! mcgpu_warp_geometry: bad argument (the context needs a device)");
+  HostModel& H = ctx->host;
+  DeviceModel& D = ctx->dev;
+  require(D.vol_kind == kVolU8, -5, "!!ERROR!! mcgpu_warp_geometry: needs a palette volume (<= 256 distinct (material, density) pairs); use mcgpu_set_geometry_arrays");
+  require(default_material >= 1 && default_material <= kMaxMaterials && D.compact_of[default_material - 1] >= 0, -5,
+          "!!ERROR!! mcgpu_warp_geometry: the default material has no data file in this simulation");
+  int default_index = -1;
+  {
+    char t[64];
+    snprintf(t, sizeof t, "%.6f", (double)default_density);  // densities as a voxel file would carry them
+    const float dq = strtof(t, nullptr);
+    for (int e = 0; e < D.palette_size && default_index < 0; ++e) {
+      int mc;
+      memcpy(&mc, &D.palette_host[2 * e + 1], 4);
+      if (mc == D.compact_of[default_material - 1] && D.palette_host[2 * e] == dq) default_index = e;
+    }
+  }
+  require(default_index >= 0, -5, "!!ERROR!! mcgpu_warp_geometry: the default (material, density) is not in the palette; use mcgpu_set_geometry_arrays");
+  HIP_TRY(hipSetDevice(D.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t nvox = H.voxels.count();
+  const size_t nsub = (size_t)D.sub_n[0] * D.sub_n[1] * D.sub_n[2];
+  if (!D.vol_base) {  // first call: what is resident now is the base geometry of every later warp
+    D.vol_base = D.put(std::vector<unsigned char>(nvox, 0));
+    HIP_TRY(hipMemcpy(D.vol_base, D.vol, nvox, hipMemcpyDeviceToDevice));
+    D.sub_first = D.put(std::vector<unsigned short>(nsub, 0));
+    D.brick_first = D.put(std::vector<unsigned short>((size_t)D.brick_count, 0));
+    D.code_of_dev = D.put(std::vector<unsigned char>(D.code_of, D.code_of + 256));
+    D.rebuild_out = D.put(std::vector<unsigned int>(32, 0u));
+    D.dvf = D.put(std::vector<float>(3 * nvox, 0.f));
+  }
+  HIP_TRY(hipMemcpy(D.dvf, displacement, 3 * nvox * 4, hipMemcpyHostToDevice));
+  GeometryRebuild g;
+  g.nx = H.voxels.n[0]; g.ny = H.voxels.n[1]; g.nz = H.voxels.n[2];
+  g.brick_shift = D.brick_shift;
+  for (int k = 0; k < 3; ++k) { g.bn[k] = D.brick_n[k]; g.sn[k] = D.sub_n[k]; }
+  g.base_idx = D.vol_base; g.dvf = D.dvf; g.default_index = (unsigned char)default_index;
+  g.idx = (unsigned char*)D.vol;
+  g.sub_first = D.sub_first; g.brick_first = D.brick_first;
+  g.sub = D.sub; g.bricks = D.bricks; g.code_of = D.code_of_dev; g.background = D.background;
+  g.out = D.rebuild_out;
+  const bool allow_exterior = getenv("MCGPU_NO_EXTERIOR") == nullptr;
+  HIP_TRY(launch_geometry_rebuild(g, frame, allow_exterior, nullptr));
+  unsigned int out[17];
+  HIP_TRY(hipMemcpy(out, D.rebuild_out, sizeof out, hipMemcpyDeviceToHost));  // waits for the kernels
+  // largest density per material among the palette entries that occur -> Woodcock majorant (the only table that depends on it)
+  for (int m = 0; m < kMaxMaterials; ++m) H.voxels.density_max[m] = -999.0f;
+  for (int e = 0; e < D.palette_size; ++e)
+    if (out[e >> 5] & (1u << (e & 31))) {
+      int mc;
+      memcpy(&mc, &D.palette_host[2 * e + 1], 4);
+      for (int m = 0; m < kMaxMaterials; ++m)
+        if (D.compact_of[m] == mc) H.voxels.density_max[m] = std::max(H.voxels.density_max[m], D.palette_host[2 * e]);
+    }
+  rebuild_woodcock(H.mat, H.voxels.density_max);
+  {
+    std::vector<float> wood(2 * (size_t)H.mat.num_values);
+    for (int i = 0; i < H.mat.num_values; ++i) { wood[2 * i] = H.mat.woodcock[i].x; wood[2 * i + 1] = H.mat.woodcock[i].y; }
+    HIP_TRY(hipMemcpy(D.woodcock, wood.data(), wood.size() * 4, hipMemcpyHostToDevice));
+  }
+  D.bricks_mixed = (int)out[14]; D.bricks_exterior = (int)out[15]; D.sub_mixed = (int)out[16];
+  D.has_exterior = out[15] > 0 ? 1 : 0;
+  if (D.has_exterior) {
+    const int k = D.brick_shift;
+    for (int a = 0; a < 3; ++a) {
+      D.objbox_lo[a] = (float)((int)out[8 + a] << k) * H.voxels.voxel_size[a];
+      D.objbox_hi[a] = (float)std::min(((int)out[11 + a] + 1) << k, H.voxels.n[a]) * H.voxels.voxel_size[a];
+      D.cold_host.objbox_lo[a] = D.objbox_lo[a];
+      D.cold_host.objbox_hi[a] = D.objbox_hi[a];
+    }
+    HIP_TRY(hipMemcpy(D.cold, &D.cold_host, sizeof D.cold_host, hipMemcpyHostToDevice));
+  }
+  ctx->host_voxels_stale = true;
   ctx->table_cache.clear();
   return 0;
   ABI_END

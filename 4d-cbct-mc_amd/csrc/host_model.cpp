@@ -746,6 +746,7 @@ void load_material_files(const std::vector<std::string>& files, const VoxelGrid&
       if (nval > kMaxRayleighBins) fail(-2, "!!load_material ERROR!! Too many energy bins (Input bins=%d, MAX_ENERGYBINS_RAYLEIGH=%d)!!", nval, kMaxRayleighBins);
       if (nval < 2) fail(-2, "!!load_material ERROR!! Too few energy bins in '%s'.", files[mat].c_str());
       t.woodcock.assign(nval, Float2{99999999.99f, 0.f});
+      t.mfp_total_file.assign((size_t)nval * kMaxMaterials, 0.0);
       t.a.assign((size_t)nval * kMaxMaterials, Float3{0, 0, 0});
       t.b.assign((size_t)nval * kMaxMaterials, Float3{0, 0, 0});
     } else if (nval != t.num_values) {
@@ -759,8 +760,7 @@ void load_material_files(const std::vector<std::string>& files, const VoxelGrid&
       double d_e, d_ray, d_co, d_ph, d_tot, d_pmax;
       if (sscanf(line.c_str(), "  %le  %le  %le  %le  %le  %le", &d_e, &d_ray, &d_co, &d_ph, &d_tot, &d_pmax) != 6)
         fail(-2, "!!load_material ERROR!! Could not read mean free path row %d in '%s'.", i, files[mat].c_str());
-      const float temp_mfp = (float)(d_tot * t.density_nominal[mat] / density_max[mat]);
-      if (temp_mfp < t.woodcock[i].x) t.woodcock[i].x = temp_mfp;
+      t.mfp_total_file[(size_t)i * kMaxMaterials + mat] = d_tot;
       Float3& a = t.a[(size_t)i * kMaxMaterials + mat];
       a.x = (float)(1.0 / (d_tot * t.density_nominal[mat]));
       a.y = (float)(1.0 / (d_co * t.density_nominal[mat]));
@@ -834,10 +834,29 @@ void load_material_files(const std::vector<std::string>& files, const VoxelGrid&
     }
   }
   if (t.num_values < 2) fail(-2, "!!load_material ERROR!! No material data were read (the first material file fixes the energy grid).");
-  // Woodcock slope and re-basing (:2433-2441).  The reference stops the slope loop one entry short
-  // and then re-bases the last entry with uninitialised memory; here the last bin re-uses the
-  // previous slope (only reachable for E == table maximum).
+  rebuild_woodcock(t, v.density_max);
+}
+
+// Woodcock majorant: minimum over the materials in the volume of mfp_total * rho_nominal / rho_max(material) per energy
+// bin (:2294-2296), then slope and re-basing (:2433-2441).  The reference stops the slope loop one entry short and then
+// re-bases the last entry with uninitialised memory; here the last bin re-uses the previous slope (only reachable for
+// E == table maximum).
+void rebuild_woodcock(MaterialTables& t, const float density_max_in[kMaxMaterials]) {
   const int nv = t.num_values;
+  t.woodcock.assign(nv, Float2{99999999.99f, 0.f});
+  for (int mat = 0; mat < kMaxMaterials; ++mat) {
+    if (!t.used[mat]) continue;
+    float dmax = density_max_in[mat];
+    if (!(dmax > 0)) {
+      if (mat == 0) dmax = 0.01f * t.density_nominal[mat];  // the first material is always loaded (:2229-2230)
+      else continue;
+    }
+    for (int i = 0; i < nv; ++i) {
+      const float temp_mfp = (float)(t.mfp_total_file[(size_t)i * kMaxMaterials + mat] * t.density_nominal[mat] / dmax);
+      if (temp_mfp < t.woodcock[i].x) t.woodcock[i].x = temp_mfp;
+    }
+  }
+  const double delta_e = t.delta_e;
   for (int i = 0; i < nv - 1; ++i) t.woodcock[i].y = (float)((t.woodcock[i + 1].x - t.woodcock[i].x) / delta_e);
   t.woodcock[nv - 1].y = t.woodcock[nv - 2].y;
   for (int i = 0; i < nv; ++i) t.woodcock[i].x = (float)(t.woodcock[i].x - (t.e0 + i * delta_e) * t.woodcock[i].y);

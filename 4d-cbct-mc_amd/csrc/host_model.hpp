@@ -80,6 +80,7 @@ struct MaterialTables {
   float density_nominal[kMaxMaterials];
   bool used[kMaxMaterials];
   std::vector<Float2> woodcock;  // [num_values]   mfp_min(E) = x + E*y
+  std::vector<double> mfp_total_file;  // [num_values*25] total mean free path as read (what the Woodcock minimum is taken over)
   std::vector<Float3> a, b;      // [num_values*25] {total, Compton, Rayleigh} inverse MFP / rho
   // Rayleigh (reference `rayleigh_struct`, MC-GPU_v1.3.h:251-264)
   std::vector<float> xco, pco, aco, bco;  // [128*25], index i + 128*mat
@@ -120,6 +121,9 @@ void load_spectrum(const std::string& path, Spectrum& s);                  // in
 void load_voxel_file(const std::string& path, VoxelGrid& v, int n_threads = 0);  // load_voxels
 void load_material_files(const std::vector<std::string>& files, const VoxelGrid& v, MaterialTables& t);  // load_material
 void load_model(const std::string& input_path, HostModel& m);              // all of the above, reference order
+// Woodcock majorant table from the total mean free paths as read and the largest density of every material in the volume
+// (load_material :2294-2296 and :2433-2441): all a geometry change needs when the set of materials stays the same
+void rebuild_woodcock(MaterialTables& t, const float density_max[kMaxMaterials]);
 
 // RANECU seed stepping between projections (update_seed_PRNG, MC-GPU_v1.3.cu:3456-3485)
 int ranecu_mul_mod(int m, int a, int s);                                   // abMODm, MC-GPU_kernel_v1.3.cu:919

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
@@ -56,19 +57,27 @@ int main(int argc, char** argv) {
   const double t_begin = now_s();
   printf("\n     *** MC CBCT projection engine for AMD MI355X (MC-GPU v1.3 file contract) ***\n\n    -- INITIALIZATION phase:\n");
   fflush(stdout);
+  // The input, the voxel file and the material files are parsed ONCE (host-only context); every device gets a clone, and
+  // the clones are built side by side (the reference parses everything in every MPI rank, MC-GPU_v1.3.cu:377-640).
+  mcgpu_ctx* parsed = nullptr;
+  if (mcgpu_create(argv[1], -1, &parsed) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 254; }
+  std::vector<int> devs(ngpu, 0);
+  for (int g = 0; g < ngpu; ++g) devs[g] = device_list.empty() ? g : device_list[g];
+  if (ngpu == 1 && device_list.empty()) {  // single GPU: the input file's GPU number
+    long long gpu_id = 0;
+    mcgpu_config_i64(parsed, "gpu_id", &gpu_id);
+    devs[0] = gpu_id > 0 ? (int)gpu_id : 0;
+  }
   std::vector<mcgpu_ctx*> ctx(ngpu, nullptr);
-  for (int g = 0; g < ngpu; ++g) {
-    // single GPU: the input file's GPU number; several: devices 0..N-1 (or the explicit list)
-    int dev = device_list.empty() ? g : device_list[g];
-    if (ngpu == 1 && device_list.empty()) {
-      mcgpu_ctx* probe = nullptr;
-      long long gpu_id = 0;
-      if (mcgpu_create(argv[1], -1, &probe) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 254; }
-      mcgpu_config_i64(probe, "gpu_id", &gpu_id);
-      mcgpu_destroy(probe);
-      dev = gpu_id > 0 ? (int)gpu_id : 0;
-    }
-    if (mcgpu_create(argv[1], dev, &ctx[g]) != 0) { printf("\n\n   %s\n\n", mcgpu_last_error()); return 254; }
+  {
+    std::vector<std::string> err(ngpu);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ngpu; ++g)
+      th.emplace_back([&, g] { if (mcgpu_clone(parsed, devs[g], &ctx[g]) != 0) err[g] = mcgpu_last_error(); });  // the last error is per thread
+    for (auto& t : th) t.join();
+    mcgpu_destroy(parsed);
+    for (int g = 0; g < ngpu; ++g)
+      if (!ctx[g]) { printf("\n\n   %s\n\n", err[g].empty() ? "!!ERROR!! device context could not be created" : err[g].c_str()); return 254; }
   }
   long long det_nx = 0;
   mcgpu_config_i64(ctx[0], "num_pixels_x", &det_nx);

@@ -1,10 +1,14 @@
 // warp.hip -- nearest-neighbour warp of a voxelised geometry by a dense displacement field.
 //
-// The reference warps materials and densities per respiratory state on the CPU with vroc's SpatialTransformer
+// The reference warps materials and densities per respiratory state with vroc's SpatialTransformer
 // (cbctmc/mc/geometry.py:386-439; vroc is a third-party dependency that is not vendored in the reference tree): identity
-// grid + displacement, torch.nn.functional.grid_sample(mode="nearest", align_corners=True), voxels sampled from outside
-// the volume get a default (air).  Restated: out[x] = in[rint(x + u(x))] per axis (round-half-even, as nearbyint),
-// default when any rounded coordinate falls outside.  HBM-bound gather: 12 B of field + 5 B read + 5 B written per voxel.
+// grid + displacement, normalised to [-1, 1] per axis, torch.nn.functional.grid_sample(mode="nearest", align_corners=True),
+// voxels sampled from outside the volume get a default (air).  Restated with torch's own float32 steps, because the
+// detour through normalised coordinates moves ties and border samples (out[x] = in[rint(x + u)] differs in 212 of the
+// 2.1e5 known answers of tests/golden/warp_kat.npz, generated with torch by oracle/gen_warp_golden.py):
+//     t = 2 * ((x + u) / (n - 1) - 0.5);   s = ((t + 1) / 2) * (n - 1);   source voxel = nearbyint(s), inside iff 0 <= s' <= n - 1
+// every operation rounded to float32 (IEEE division, no contraction: this file is built with -ffp-contract=off).
+// HBM-bound gather: 12 B of field + 5 B read + 5 B written per voxel.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -18,7 +22,11 @@ __global__ __launch_bounds__(256) void warp_kernel(int nx, int ny, int nz, const
   const size_t nvox = (size_t)nx * ny * nz;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((size_t)nx * ny));
-    const float sx = rintf((float)x + dvf[i]), sy = rintf((float)y + dvf[nvox + i]), sz = rintf((float)z + dvf[2 * nvox + i]);
+    auto sample = [](float loc, int n) {
+      const float t = 2.0f * (__fdiv_rn(loc, (float)(n - 1)) - 0.5f);
+      return rintf(((t + 1.0f) / 2.0f) * (float)(n - 1));
+    };
+    const float sx = sample((float)x + dvf[i], nx), sy = sample((float)y + dvf[nvox + i], ny), sz = sample((float)z + dvf[2 * nvox + i], nz);
     unsigned char m = default_mat;
     float d = default_dens;
     if (sx >= 0.f && sx <= (float)(nx - 1) && sy >= 0.f && sy <= (float)(ny - 1) && sz >= 0.f && sz <= (float)(nz - 1)) {

@@ -22,13 +22,13 @@ EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
 
 # every symbol declared in include/mcgpu_amd.h
 ABI_SYMBOLS = (
-    "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
+    "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_clone", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
-    "mcgpu_warp_volume",
+    "mcgpu_warp_volume", "mcgpu_warp_geometry",
     "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule",
 )
 
@@ -74,6 +74,7 @@ def load_library(path: Optional[os.PathLike] = None):
     vp, cp, ci, cull = C.c_void_p, C.c_char_p, C.c_int, C.c_ulonglong
     lib.mcgpu_last_error.restype = cp
     lib.mcgpu_create.argtypes = [cp, ci, C.POINTER(vp)]
+    lib.mcgpu_clone.argtypes = [vp, ci, C.POINTER(vp)]
     lib.mcgpu_destroy.argtypes = [vp]
     lib.mcgpu_destroy.restype = None
     lib.mcgpu_config_i64.argtypes = [vp, cp, C.POINTER(C.c_longlong)]
@@ -102,6 +103,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_set_projection_angles.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.mcgpu_set_geometry_arrays.argtypes = [vp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_warp_volume.argtypes = [vp, C.POINTER(ci), vp, vp, vp, ci, C.c_float, vp, vp]
+    lib.mcgpu_warp_geometry.argtypes = [vp, vp, ci, ci, C.c_float]
     lib.mcgpu_stack_finish.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.mcgpu_stack_read.argtypes = [cp, C.POINTER(ci), vp, C.c_size_t]
     lib.mcgpu_normalize_stack.argtypes = [cp, cp, C.c_double, C.c_double, cp, C.c_double, C.c_double]
@@ -204,13 +206,20 @@ def normalize_stack(total_stack, air_stack, out_stack, sigma=(10.0, 10.0), spaci
 class Context:
     """One loaded simulation (input file + tables), optionally resident on one GPU."""
 
-    def __init__(self, input_path, device: int = 0):
+    def __init__(self, input_path, device: int = 0, _clone_of: "Context" = None):
         self.lib = load_library()
         h = C.c_void_p()
-        _check(self.lib.mcgpu_create(str(input_path).encode(), int(device), C.byref(h)))
+        if _clone_of is not None:
+            _check(self.lib.mcgpu_clone(_clone_of.h, int(device), C.byref(h)))
+        else:
+            _check(self.lib.mcgpu_create(str(input_path).encode(), int(device), C.byref(h)))
         self.h = h
         self.device = device
         self.input_path = str(input_path)
+
+    def clone(self, device: int = 0) -> "Context":
+        """The same simulation on another device without parsing the input files again (mcgpu_clone)."""
+        return Context(self.input_path, device, _clone_of=self)
 
     # -- lifecycle
     def close(self):
@@ -353,6 +362,18 @@ class Context:
         mats, dens, spacing_cm = geometry.mcgpu_arrays()
         nx, ny, nz = mats.shape
         self.set_geometry_arrays((nx, ny, nz), spacing_cm, np.transpose(mats, (2, 1, 0)), np.transpose(dens, (2, 1, 0)))
+
+    def warp_geometry(self, displacement: np.ndarray, frame: str = "geometry", default_material: int = 1, default_density: float = 0.0013):
+        """The context's geometry := warp(base geometry, displacement) entirely on the device (mcgpu_warp_geometry).
+        frame "geometry": displacement [3, gx, gy, gz] in the frame of the MCGeometry arrays (what the reference's
+        correspondence model predicts; the rot90 of the voxel file is handled on the device); frame "engine": [3, nz, ny, nx].
+        Raises EngineError(-5) when the volume is not a palette volume: fall back to warp_volume + set_geometry."""
+        u = np.ascontiguousarray(displacement, dtype=np.float32)
+        nx, ny, nz = self.geti("num_voxels_x"), self.geti("num_voxels_y"), self.geti("num_voxels_z")
+        want = (3, ny, nx, nz) if frame == "geometry" else (3, nz, ny, nx)
+        if u.shape != want:
+            raise ValueError(f"displacement of shape {u.shape}, expected {want} for frame '{frame}'")
+        _check(self.lib.mcgpu_warp_geometry(self.h, u.ctypes.data, 1 if frame == "geometry" else 0, int(default_material), float(default_density)))
 
     def warp_volume(self, material_zyx: np.ndarray, density_zyx: np.ndarray, displacement: np.ndarray, default_material: int, default_density: float):
         """Nearest-neighbour warp on the GPU: out[x] = in[rint(x + u(x))]; displacement [3, nz, ny, nx] (x, y, z components, voxels)."""

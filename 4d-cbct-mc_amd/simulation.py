@@ -292,6 +292,21 @@ class MCSimulation4D:
         m, d = ctx.warp_volume(np.transpose(mats, (2, 1, 0)), np.transpose(dens, (2, 1, 0)), u, material_number("air"), MATERIALS_125KEV["air"])
         return MCGeometry(np.transpose(m, (2, 1, 0)), np.transpose(d, (2, 1, 0)), self.geometry.image_spacing)
 
+    def apply_state(self, ctx, engine, signal: float, dt_signal: float):
+        """Geometry of one respiratory state on the resident context: warped on the device from the predicted field
+        (mcgpu_warp_geometry: nothing but the field crosses PCIe); volumes that are not palette volumes take the route
+        through host arrays (warp_volume + set_geometry)."""
+        import numpy as np
+        field = np.asarray(self.correspondence_model.predict(np.array([signal, dt_signal])), dtype=np.float32)
+        if field.ndim == 5:
+            field = field[0]
+        try:
+            ctx.warp_geometry(field, frame="geometry")
+        except engine.EngineError as e:
+            if e.code != -5:
+                raise
+            ctx.set_geometry(self.warp_geometry(ctx, signal, dt_signal))
+
     def run_simulation(self, respiratory_signal, respiratory_signal_quantization, output_folder, engine, gpu_ids=(0,), mode="fast",
                        run_air_simulation=False, air_projection_denoise_kernel_size=(10, 10), air_n_histories=int(5e10), start_angle=270.0,
                        force_rerun=False):
@@ -331,7 +346,7 @@ class MCSimulation4D:
         ctx = engine.create(str(input_filepath), device=gpu_ids[0])
         try:
             for (s, ds), indices in unique.items():
-                ctx.set_geometry(self.warp_geometry(ctx, s, ds))
+                self.apply_state(ctx, engine, s, ds)
                 angles = [start_angle + i * self.angle_between_projections for i in indices]
                 ctx.set_projection_angles(angles[0:1] + angles)  # pose 0 is the input file's: skipped below (sim.py:658-660)
                 ctx.run_scan(mode=mode, first_projection=1, num_projections=len(angles), crop_nx=half_fan, write_stacks=False,

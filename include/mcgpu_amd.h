@@ -46,6 +46,11 @@ const char *mcgpu_last_error(void);
  * device and upload all tables.  device_id < 0 builds the host model only (no HIP call is made). */
 int mcgpu_create(const char *input_path, int device_id, mcgpu_ctx **out);
 void mcgpu_destroy(mcgpu_ctx *ctx);
+/* A second context of the same simulation on another device (device_id < 0: host only) without parsing the input, the
+ * voxel file and the material files again: what each further rank of the reference's `mpirun -n N` repeats in full
+ * (MC-GPU_v1.3.cu:377-640: every MPI process runs read_input / load_voxels / load_material).  The clone is independent
+ * of `src` afterwards. */
+int mcgpu_clone(const mcgpu_ctx *src, int device_id, mcgpu_ctx **out);
 
 /* Scalars parsed from the input file (MC-GPU_v1.3.cu:1280-1615).  Keys: "total_histories", "seed",
  * "gpu_id", "threads_per_block", "histories_per_thread", "num_projections", "enable_specific_angles",
@@ -184,6 +189,20 @@ int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan
  * finalized and written as above.  Tally buffers are double-buffered per device: no device waits for the reduce.  Dose
  * tallies stay per context (sum them with mcgpu_dose_read). */
 int mcgpu_run_scan_multi(mcgpu_ctx *const *ctxs, int n_ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
+
+/* Replace the context's geometry by warp(base geometry, displacement) WITHOUT leaving the device: what
+ * MCSimulation4D does per respiratory state with `MCGeometry.warp` + a new voxel file + a new engine process
+ * (cbctmc/mc/simulation.py:643-692, cbctmc/mc/geometry.py:386-439).  The base geometry is the one resident at the first
+ * call.  displacement: host floats in voxels; frame 0: [3][nz][ny][nx] in the engine's frame (components x, y, z); frame 1:
+ * [3][gx][gy][gz] in the frame of the reference's MCGeometry arrays, of which the engine volume is the rot90(k=3) in the x/y
+ * plane (cbctmc/mc/geometry.py:589-599) -- the field CorrespondenceModel.predict returns, as it is.  Nearest neighbour with
+ * the float32 arithmetic of the grid_sample(nearest, align_corners=True) the reference calls, evaluated in the field's own frame
+ * (tests/golden/warp_kat.npz); voxels sampled from outside get (default_material,
+ * default_density), which must be in the palette (air at 0.0013 always is).  Palette index volume, both brick levels, the
+ * object box and the Woodcock majorant are rebuilt on the device (+ a 24001-entry table on the host); needs a palette
+ * volume (<= 256 (material, density) pairs), else -5: fall back to mcgpu_warp_volume + mcgpu_set_geometry_arrays.
+ * Dose tallies keep accumulating across such changes. */
+int mcgpu_warp_geometry(mcgpu_ctx *ctx, const float *displacement, int frame, int default_material, float default_density);
 
 /* ---- 4-D: one resident context for many (geometry, projection angles) jobs (cbctmc/mc/simulation.py:527-710 launches the
  * engine once per respiratory state) ----

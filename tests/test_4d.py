@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 
 import cases
+import golden_util as gu
+import warp_ref
 
 
 def _slab():
@@ -69,22 +71,93 @@ def test_respiratory_signal_rules():
     assert sorted(i for v in u.values() for i in v) == list(range(300))
 
 
+def test_warp_restatement_equals_torch_grid_sample_fixture():
+    """tests/warp_ref.py (numpy) against the known answers torch itself produced (oracle/gen_warp_golden.py): ties, both
+    borders of every axis within a few ulps, far-away samples, default values."""
+    g = gu.load("warp_kat.npz")
+    for k in range(int(g["n_cases"])):
+        wm, wd = warp_ref.warp_nearest(g[f"materials_{k}"], g[f"densities_{k}"], g[f"field_{k}"], int(g["default_material"]), float(g["default_density"]))
+        assert np.array_equal(wm, g[f"warped_materials_{k}"]) and np.array_equal(wd, g[f"warped_densities_{k}"]), k
+    # the shortcut out[x] = in[rint(x + u)] is NOT the same function (ties and border samples move through the normalisation)
+    m, d, u = g["materials_1"], g["densities_1"], g["field_1"]
+    idx = np.stack(np.meshgrid(*[np.arange(n) for n in m.shape], indexing="ij")).astype(np.float32)
+    s = [np.rint(idx[c] + u[c]) for c in range(3)]
+    inside = np.all([(s[c] >= 0) & (s[c] <= m.shape[c] - 1) for c in range(3)], axis=0)
+    i = [np.clip(s[c], 0, m.shape[c] - 1).astype(int) for c in range(3)]
+    assert np.count_nonzero(np.where(inside, m[i[0], i[1], i[2]], 1) != g["warped_materials_1"]) > 0
+
+
 @pytest.mark.gpu
-def test_gpu_warp_matches_numpy_nearest_neighbour(engine, case_dir):
-    rng = np.random.default_rng(2)
-    nz, ny, nx = 11, 13, 17
-    m = rng.integers(1, 22, (nz, ny, nx)).astype(np.uint8)
-    d = rng.uniform(0.001, 2.7, (nz, ny, nx)).astype(np.float32)
-    u = rng.uniform(-4, 4, (3, nz, ny, nx)).astype(np.float32)
-    u[:, 0, 0, :6] = [[0.5, 1.5, 2.5, -0.5, -1.5, 0.0]] * 3  # ties: round half to even
+def test_gpu_warp_equals_torch_grid_sample_fixture(engine, case_dir):
+    """csrc/warp.hip through the C ABI (and MCGeometry.warp on top of it) against the torch-generated known answers."""
+    g = gu.load("warp_kat.npz")
     with engine.create(case_dir("air"), device=0) as ctx:
-        mo, do = ctx.warp_volume(m, d, u, default_material=1, default_density=0.0012)
-    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-    sx, sy, sz = (np.rint(x.astype(np.float32) + u[0]), np.rint(y.astype(np.float32) + u[1]), np.rint(z.astype(np.float32) + u[2]))
-    inside = (sx >= 0) & (sx <= nx - 1) & (sy >= 0) & (sy <= ny - 1) & (sz >= 0) & (sz <= nz - 1)
-    ix, iy, iz = [np.clip(a, 0, n - 1).astype(int) for a, n in ((sx, nx), (sy, ny), (sz, nz))]
-    assert np.array_equal(mo, np.where(inside, m[iz, iy, ix], 1))
-    assert np.array_equal(do, np.where(inside, d[iz, iy, ix], np.float32(0.0012)))
+        for k in range(int(g["n_cases"])):
+            m, d, u = g[f"materials_{k}"], g[f"densities_{k}"], g[f"field_{k}"]  # [x, y, z], field [3, x, y, z]
+            mo, do = ctx.warp_volume(np.transpose(m, (2, 1, 0)), np.transpose(d, (2, 1, 0)), np.ascontiguousarray(np.transpose(u, (0, 3, 2, 1))),
+                                     default_material=int(g["default_material"]), default_density=float(g["default_density"]))
+            assert np.array_equal(np.transpose(mo, (2, 1, 0)), g[f"warped_materials_{k}"]), k
+            assert np.array_equal(np.transpose(do, (2, 1, 0)), g[f"warped_densities_{k}"]), k
+        geo = cases.geometry.MCGeometry(g["materials_3"], g["densities_3"], (2.0, 2.0, 2.0))
+        # MCGeometry.warp: air (material 1, density 0.0013) outside, [1, 3, x, y, z] fields accepted like the reference
+        w = geo.warp(g["field_3"][None], ctx)
+        assert np.array_equal(w.materials, g["warped_materials_3"]) and np.array_equal(w.densities, g["warped_densities_3"])
+        assert w.image_spacing == geo.image_spacing
+        with pytest.raises(ValueError):
+            geo.warp(g["field_2"], ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cirs76", "slab4d"])
+def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, case):
+    """mcgpu_warp_geometry (index volume warped, both brick levels, object box and Woodcock majorant rebuilt on the device)
+    against the route through the host: warp in the MCGeometry frame (tests/warp_ref.py, pinned by the torch fixture), a
+    fresh context on the warped voxel file.  Same host tables, same COMPAT tallies bit for bit, same FAST tallies."""
+    mats, spc = cases.material_files(), cases.spectrum_file()
+    if case == "cirs76":
+        g = cases.CASES["cirs76"][0]()
+    else:
+        g = _slab()
+    rng = np.random.default_rng(5)
+    shape = g.materials.shape
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n, dtype=np.float32) for n in shape], indexing="ij")
+    field = np.stack([2.5 * np.sin(2.0 * y) + 0.5, 1.5 * x * z - 0.5, 3.0 * np.cos(1.5 * x) * (1 - z * z)]).astype(np.float32)
+    field[:, ::7, ::5, ::3] += rng.uniform(-3, 3, size=field[:, ::7, ::5, ::3].shape).astype(np.float32)
+    field[0, 1, :, :] = 0.5  # ties along the first axis
+    kw = dict(n_projections=2, angle_between_projections=70.0, n_histories=200_000, **cases.SMALL_DET)
+    base = cases.simulation.MCSimulation(g, mats, spc, **kw).prepare_simulation(tmp_path / "base")
+    air = cases.materials.material_number("air")
+    wm, wd = warp_ref.warp_nearest(g.materials, g.densities, field, air, cases.materials.MATERIALS_125KEV["air"])
+    assert (wm != g.materials).sum() > 100
+    warped = cases.simulation.MCSimulation(cases.geometry.MCGeometry(wm, wd, g.image_spacing), mats, spc, **kw).prepare_simulation(tmp_path / "warped")
+    with engine.create(base, device=0) as dev, engine.create(warped, device=0) as ref:
+        before = dev.host_table("mfp_woodcock").copy()
+        dev.warp_geometry(field, frame="geometry")
+        assert np.array_equal(dev.host_table("voxel_mat_dens"), ref.host_table("voxel_mat_dens"))  # downloaded on demand
+        assert np.array_equal(dev.host_table("density_max").view("<f4")[:22] > 0, ref.host_table("density_max").view("<f4")[:22] > 0)
+        assert np.array_equal(dev.host_table("mfp_woodcock"), ref.host_table("mfp_woodcock"))
+        for key in ("bricks_mixed", "bricks_exterior", "brick_shift", "brick_count"):
+            assert dev.geti(key) == ref.geti(key), key
+        for p in range(2):
+            a, _, _ = dev.run_projection(p, 300, mode="compat", seed=5 + p, hpt=100)
+            b, _, _ = ref.run_projection(p, 300, mode="compat", seed=5 + p, hpt=100)
+            assert np.array_equal(a, b) and a.sum() > 0
+            a, _, _ = dev.run_projection(p, 400_000, mode="fast", seed=9)
+            b, _, _ = ref.run_projection(p, 400_000, mode="fast", seed=9)
+            assert np.array_equal(a, b) and a.sum() > 0
+        # a second state warps the BASE geometry again (not the warped one), and the identity field restores it
+        dev.warp_geometry(np.zeros_like(field), frame="geometry")
+        with engine.create(base, device=0) as fresh:
+            assert np.array_equal(dev.host_table("voxel_mat_dens"), fresh.host_table("voxel_mat_dens"))
+            assert np.array_equal(dev.host_table("mfp_woodcock"), before)
+            a, _, _ = dev.run_projection(1, 300_000, mode="fast", seed=3)
+            b, _, _ = fresh.run_projection(1, 300_000, mode="fast", seed=3)
+            assert np.array_equal(a, b)
+        # the engine-frame form of the same call: the field rotated like the voxel file (rot90 k=3: x_e = y_g, y_e = -x_g)
+        fe = np.stack([np.rot90(field[1], k=3, axes=(0, 1)), -np.rot90(field[0], k=3, axes=(0, 1)), np.rot90(field[2], k=3, axes=(0, 1))])
+        dev.warp_geometry(np.ascontiguousarray(np.transpose(fe, (0, 3, 2, 1))), frame="engine")
+        differ = np.count_nonzero(dev.host_table("voxel_mat_dens").view("<f4") != ref.host_table("voxel_mat_dens").view("<f4"))
+        assert differ < 0.01 * wm.size  # same warp up to ties and border samples on the mirrored axis
 
 
 @pytest.mark.gpu
@@ -107,12 +180,7 @@ def test_4d_scan_equals_per_state_file_based_runs(engine, tmp_path):
     planes = np.zeros((12, 3, 96, 231), dtype=np.float32)
     for k, ((sv, dsv), idx) in enumerate(R.get_unique_signals(s, ds).items()):
         u = model.predict(np.array([sv, dsv]))
-        x, y, z = np.meshgrid(*[np.arange(n) for n in g.materials.shape], indexing="ij")
-        src = [np.rint(a.astype(np.float32) + u[c]) for c, a in enumerate((x, y, z))]
-        inside = np.all([(src[c] >= 0) & (src[c] <= g.materials.shape[c] - 1) for c in range(3)], axis=0)
-        sx, sy, sz = [np.clip(src[c], 0, g.materials.shape[c] - 1).astype(int) for c in range(3)]
-        wm = np.where(inside, g.materials[sx, sy, sz], cases.materials.material_number("air")).astype(np.uint8)
-        wd = np.where(inside, g.densities[sx, sy, sz], np.float32(cases.materials.MATERIALS_125KEV["air"])).astype(np.float32)
+        wm, wd = warp_ref.warp_nearest(g.materials, g.densities, u, cases.materials.material_number("air"), cases.materials.MATERIALS_125KEV["air"])
         angles = [270.0 + i * 30.0 for i in idx]
         one = cases.simulation.MCSimulation(cases.geometry.MCGeometry(wm, wd, g.image_spacing), mats, spc, n_histories=200_000,
                                             projection_angles=angles[0:1] + angles, angle_between_projections=30.0, **cases.SMALL_DET)

@@ -257,3 +257,19 @@ def test_mpirun_shim_translates_the_reference_command_line(tmp_path):
     assert run("-np", "8", str(probe), "a b.in") == "[a b.in][--gpus][8]"       # spaces survive
     assert run(str(probe), "input.in") == "[input.in][--gpus][1]"                # no -n: one rank
     assert run("--tag-output", "-v", "-n", "4", "/bin/echo", "in") == "in --gpus 4"
+
+
+def test_clone_shares_the_parsed_model(engine, case_dir):
+    """mcgpu_clone: a further context of the same simulation without parsing anything again (one per device in the
+    executable's --gpus path); host tables and configuration are those of the parsed context, and it outlives it."""
+    src = engine.create(case_dir("slab_angles"), device=-1)
+    twin = src.clone(device=-1)
+    names = ("voxel_mat_dens", "mfp_woodcock", "mfp_a", "source_data", "detector_data", "espc_alias", "noscco")
+    want = {n: src.host_table(n).copy() for n in names}
+    nproj, seed = src.num_projections, src.geti("seed")
+    src.close()
+    for n in names:
+        assert np.array_equal(twin.host_table(n), want[n]), n
+    assert twin.num_projections == nproj == 3 and twin.geti("seed") == seed
+    assert twin.projection_file_name(1).endswith("projection_300.500000deg")
+    twin.close()
