@@ -36,6 +36,7 @@ constexpr int kBatch = 8;
 struct ProjParam {  // per projection, wave-uniform in the kernels
   float c, s;       // cos / sin of the gantry angle
   float off_x, off_y;
+  float gap;        // angular weight [rad]: half the distance to both neighbouring projections (RTK GetAngularGaps)
 };
 
 // in: [n][nv][nu] raw line integrals; out: [n][nv][nu_p] weighted rows, padded with pad_l zero columns on the left (and zeros on the
@@ -122,7 +123,7 @@ struct BackArgs {
   int nx, ny, nz, nu, nv, nb;  // nb = projections in this batch; nu = usable columns
   int stride;                  // floats per detector row in q
   float x0, y0, z0, sx, sy, sz;
-  float sid, sdd, inv_du, inv_dv, u0, v0, dbeta;
+  float sid, sdd, inv_du, inv_dv, u0, v0;
   ProjParam pp[kBatch];
 };
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 4) void backproject_kernel(float* __restrict__
         iu[k] = i;
         au[k] = fu - fl;
         const float r = A.sid / U;
-        wg[k] = A.dbeta * r * r;
+        wg[k] = A.pp[k].gap * r * r;
         av_a[k] = mag * A.inv_dv;                                  // fv = av_a * Y + av_b
         av_b[k] = (-A.pp[k].off_y - A.v0) * A.inv_dv;
       }
@@ -299,8 +300,41 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     for (int k = 0; k < n; ++k) {
       const double t = o->gantry_deg[k] * M_PI / 180.0;
       const double ox = o->proj_offset_x ? o->proj_offset_x[k] : 0.0, oy = o->proj_offset_y ? o->proj_offset_y[k] : 0.0;
-      pp[k] = {(float)std::cos(t), (float)std::sin(t), (float)ox, (float)oy};
+      pp[k] = {(float)std::cos(t), (float)std::sin(t), (float)ox, (float)oy, 0.f};
       displaced_weights(nu, o->du, o->u0, ox, o->sdd, &wdis[(size_t)k * nu]);
+    }
+    {
+      // Angular weight of a projection = half the distance to its two neighbours on the circle (what rtkfdk takes from
+      // the geometry file: ThreeDCircularProjectionGeometry::GetAngularGaps); 2 pi / n only for a uniform full arc.
+      // Projections at the same angle share their gap.
+      std::vector<std::pair<double, int>> by_angle(n);
+      for (int k = 0; k < n; ++k) {
+        double a = std::fmod(o->gantry_deg[k], 360.0);
+        if (a < 0) a += 360.0;
+        by_angle[k] = {a, k};
+      }
+      std::sort(by_angle.begin(), by_angle.end());
+      std::vector<double> uniq;
+      std::vector<int> count;
+      for (int k = 0; k < n; ++k) {
+        if (uniq.empty() || by_angle[k].first - uniq.back() > 1e-9) { uniq.push_back(by_angle[k].first); count.push_back(1); }
+        else ++count.back();
+      }
+      const int m = (int)uniq.size();
+      int u = -1;
+      double last = -1.0;
+      for (int k = 0; k < n; ++k) {
+        if (u < 0 || by_angle[k].first - last > 1e-9) { ++u; last = uniq[u]; }
+        double gap = 360.0;
+        if (m > 1) {
+          const double prev = uniq[(u + m - 1) % m], next = uniq[(u + 1) % m];
+          double d = next - prev;
+          if (d <= 0) d += 360.0;
+          gap = 0.5 * d;
+          if (m == 2) gap = 180.0;
+        }
+        pp[by_angle[k].second].gap = (float)(gap * M_PI / 180.0 / count[u]);
+      }
     }
     const double ox0 = std::isnan(o->ox) ? -(o->nx - 1) / 2.0 * o->sx : o->ox, oy0 = std::isnan(o->oy) ? -(o->ny - 1) / 2.0 * o->sy : o->oy,
                  oz0 = std::isnan(o->oz) ? -(o->nz - 1) / 2.0 * o->sz : o->oz;
@@ -407,8 +441,8 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
         A.nx = o->nx; A.ny = o->ny; A.nz = o->nz; A.nu = nu_p; A.stride = stride; A.nv = nv; A.nb = std::min(kBatch, m - b);
         A.x0 = (float)ox0; A.y0 = (float)oy0; A.z0 = (float)oz0; A.sx = (float)o->sx; A.sy = (float)o->sy; A.sz = (float)o->sz;
         A.sid = (float)o->sid; A.sdd = (float)o->sdd; A.inv_du = (float)(1.0 / o->du); A.inv_dv = (float)(1.0 / o->dv);
-        A.u0 = (float)u0_p; A.v0 = (float)o->v0; A.dbeta = (float)(2.0 * M_PI / n);
-        for (int k = 0; k < kBatch; ++k) A.pp[k] = (k < A.nb) ? pp[first + b + k] : ProjParam{1.f, 0.f, 0.f, 0.f};
+        A.u0 = (float)u0_p; A.v0 = (float)o->v0;
+        for (int k = 0; k < kBatch; ++k) A.pp[k] = (k < A.nb) ? pp[first + b + k] : ProjParam{1.f, 0.f, 0.f, 0.f, 0.f};
         hipLaunchKernelGGL(backproject_kernel, dim3((unsigned)((o->nx + 255) / 256), (unsigned)o->nz), dim3(256), 0, nullptr, d_vol,
                            filtered + (size_t)b * plane_p, A);
       }

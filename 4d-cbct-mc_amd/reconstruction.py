@@ -184,7 +184,19 @@ def reconstruct_3d(projections_filepath, geometry_filepath, output_folder=None, 
                    dimension: Tuple[int, int, int] = (464, 250, 464), spacing: Tuple[float, float, float] = (1.0, 1.0, 1.0), pad: float = 1.0,
                    hann: float = 1.0, hann_y: float = 1.0, water_pre_correction: Optional[Sequence[float]] = None, gpu_id: int = 0, **kwargs):
     """cbctmc/reconstruction/reconstruction.py:22-69 with `rtkfdk --hardware cuda` replaced by the in-process kernels.
-    `pad` is accepted for compatibility: rows are zero-padded for the linear convolution, there is no edge extrapolation."""
+    What each stage restates of `rtkfdk` with the options the reference passes (reconstruction.py:52-66): `--wpc` =
+    rtk::WaterPrecorrectionImageFilter (polynomial in the line integral); displaced detector =
+    rtk::DisplacedDetectorImageFilter (Wang weights + padding to a detector symmetric about the central ray); cosine and
+    angular weights = rtk::FDKWeightProjectionFilter (angular gaps from the geometry file, as here); ramp =
+    rtk::FFTRampImageFilter with `--hann` / `--hannY` windows; back-projection = rtk::FDKBackProjectionImageFilter
+    (voxel-driven, bilinear); `--short 360` leaves rtk::ParkerShortScanImageFilter inactive for a full arc.
+    `--pad` (RTK: TruncationCorrection, mirror-and-feather extrapolation of truncated rows by `pad` x width before the
+    ramp) is NOT implemented: rows are zero-padded for the linear convolution only.  With the reference's default
+    pad=1.0 a truncated object (a thorax wider than the half-fan field of view) therefore shows brighter edges here
+    than in RTK; a warning says so.  Parity against RTK itself is unpinned (RTK is absent here)."""
+    if pad:
+        import warnings
+        warnings.warn("reconstruct_3d: `pad` (RTK's truncation correction) is not implemented; rows are zero-padded only", stacklevel=2)
     projections_filepath, geometry_filepath = Path(projections_filepath), Path(geometry_filepath)
     output_folder = Path(output_folder) if output_folder else projections_filepath.parent / "reconstructions"
     output_filename = output_filename or "recon_fdk3d.mha"

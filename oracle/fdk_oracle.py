@@ -86,6 +86,23 @@ def symmetric_padding(nu, du, u0, off_min, off_max):
     return pad_l, pad_r
 
 
+def angular_gaps(gantry_deg):
+    """Angular weight of every projection [rad]: half the distance to its two neighbours on the circle (the rule of RTK's
+    ThreeDCircularProjectionGeometry::GetAngularGaps, which rtkfdk's FDKWeightProjectionFilter uses); projections at the
+    same angle share their gap.  2 pi / n for a uniform full arc."""
+    a = np.mod(np.asarray(gantry_deg, dtype=np.float64), 360.0)
+    uniq, inverse, counts = np.unique(np.round(a, 9), return_inverse=True, return_counts=True)
+    m = uniq.size
+    if m == 1:
+        gaps = np.array([360.0])
+    elif m == 2:
+        gaps = np.array([180.0, 180.0])
+    else:
+        prev, nxt = np.roll(uniq, 1), np.roll(uniq, -1)
+        gaps = 0.5 * np.mod(nxt - prev, 360.0)
+    return np.deg2rad(gaps[inverse] / counts[inverse])
+
+
 def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, spacing, origin=None, hann=0.0, hann_y=0.0, wpc=None):
     """proj [n][nv][nu] line integrals -> volume [nz][ny][nx] (float64).  origin = centre of voxel (0,0,0); None = centred."""
     proj = np.asarray(proj, dtype=np.float64)
@@ -114,7 +131,7 @@ def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, s
     X = origin[0] + sx * np.arange(nx)
     Y = origin[1] + sy * np.arange(ny)
     Z = origin[2] + sz * np.arange(nz)
-    dbeta = 2.0 * np.pi / n
+    dbeta = angular_gaps(gantry_deg)  # [rad] per projection
     for k in range(n):
         # physical coordinates of the pixel centres relative to the central ray
         up = u0 + du * np.arange(nu) + off_x[k]
@@ -136,7 +153,7 @@ def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, s
         U = sid - zr                                   # distance from the source along the central axis
         mag = sdd / U
         fu = (mag * xr - off_x[k] - u0_p) / du         # fractional column index of the padded rows  [nz][nx]
-        wgt = dbeta * (sid / U) ** 2
+        wgt = dbeta[k] * (sid / U) ** 2
         iu = np.floor(fu).astype(np.int64)
         au = fu - iu
         ok_u = (iu >= 0) & (iu < nu_p - 1)

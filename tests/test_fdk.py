@@ -115,6 +115,31 @@ def test_hip_fdk_matches_the_oracle(hann, hann_y, off_x, wpc, monkeypatch):
     assert rep["ms_backproject"] > 0
 
 
+def test_angular_gaps_rule():
+    assert np.allclose(fo.angular_gaps(np.arange(0, 360, 4.0)), np.deg2rad(4.0))
+    g = fo.angular_gaps([0.0, 10.0, 30.0, 200.0, 350.0])
+    assert np.allclose(np.rad2deg(g), [10.0, 15.0, 95.0, 160.0, 80.0]) and abs(g.sum() - 2 * np.pi) < 1e-12
+    assert np.allclose(np.rad2deg(fo.angular_gaps([5.0, 5.0, 185.0])), [90.0, 90.0, 180.0])  # duplicates share
+
+
+@pytest.mark.gpu
+def test_hip_fdk_weights_projections_by_their_angular_gaps():
+    """A non-uniform angle set (a 60-degree wedge of views removed, two views doubled): the kernels weight every projection
+    by its angular gap like the oracle (and like rtkfdk, which takes the gaps from the geometry file), not by 2 pi / n."""
+    geo, proj, (du, dv), (u0, v0), _ = _half_fan_case(n=120, off_x=-80.0)
+    keep = np.array([k for k in range(120) if not (40 <= k < 60)] + [3, 77])
+    geo.gantry_angles = list(np.asarray(geo.gantry_angles)[keep])
+    geo.projection_offsets_x = list(np.asarray(geo.projection_offsets_x)[keep])
+    geo.projection_offsets_y = list(np.asarray(geo.projection_offsets_y)[keep])
+    proj = proj[keep]
+    dim, sp = (40, 24, 32), (6.0, 6.0, 7.0)
+    want = fo.reconstruct(proj.astype(np.float32), du, dv, u0, v0, geo.source_to_isocenter, geo.source_to_detector, geo.gantry_angles,
+                          geo.projection_offsets_x, geo.projection_offsets_y, dim, sp, hann=1.0, hann_y=0.0)
+    got, _ = recon.fdk(proj, geo, (du, dv), (u0, v0), dim, sp, hann=1.0, hann_y=0.0)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 2e-4 * scale, np.abs(got - want).max() / scale
+
+
 @pytest.mark.gpu
 def test_reconstruct_3d_file_flow(tmp_path):
     """Reference-shaped call: normalised stack + geometry.xml in, recon_fdk3d.mha (+ .yaml) out; sphere value recovered."""
