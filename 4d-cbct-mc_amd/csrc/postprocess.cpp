@@ -60,8 +60,8 @@ struct MhaStack {
   int nx = 0, ny = 0, nslices = 0, written = 0;
   long data_offset = 0;
   float min_positive = std::numeric_limits<float>::infinity();
-  std::vector<uint64_t> zeros;  // element indices of exact zeros (patched by finish)
-  bool zeros_overflow = false;
+  std::vector<uint64_t> zeros;  // element indices of the exact zeros of slices that hold only a few (patched in place by finish)
+  std::vector<uint32_t> zero_count;  // exact zeros per slice (a slice with many is rewritten whole by finish)
   std::vector<unsigned char> have;  // slices written so far (random-access writes of a 4-D scan)
 };
 
@@ -95,20 +95,35 @@ MhaStack* mha_create(const std::string& path, int nx, int ny, int nslices, doubl
   return s;
 }
 
+
+// Zero bookkeeping of one plane for the final zero replacement: minimum positive value and the number of exact zeros in one
+// branch-free pass (the scattered stack is mostly zeros at 1e8 histories: recording every position cost 5 ms per
+// projection, more than the tracking kernel); positions only when the slice holds so few that finish patches them in place.
+static constexpr size_t kFewZeros = 64;
+static void note_zeros(MhaStack* s, int k, const float* plane) {
+  const size_t n = (size_t)s->nx * s->ny, base = (size_t)k * n;
+  if (s->zero_count.empty()) s->zero_count.assign((size_t)s->nslices, 0);
+  float mn = s->min_positive;
+  size_t nz = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float v = plane[i];
+    nz += (v == 0.0f);
+    mn = (v > 0.0f && v < mn) ? v : mn;
+  }
+  s->min_positive = mn;
+  s->zero_count[(size_t)k] = (uint32_t)nz;
+  if (nz > 0 && nz <= kFewZeros)
+    for (size_t i = 0; i < n; ++i)
+      if (plane[i] == 0.0f) s->zeros.push_back(base + i);
+}
+
 // Write slice k (any order, each slice once): a 4-D scan visits the projections grouped by respiratory state.
 void mha_write_slice(MhaStack* s, int k, const float* plane) {
   if (k < 0 || k >= s->nslices) throw Error(-3, "!!ERROR!! slice index outside " + s->path);
   if (s->have.empty()) s->have.assign((size_t)s->nslices, 0);
   if (s->have[k]) throw Error(-3, "!!ERROR!! slice written twice in " + s->path);
   const size_t n = (size_t)s->nx * s->ny, base = (size_t)k * n;
-  for (size_t i = 0; i < n; ++i) {
-    const float v = plane[i];
-    if (v > 0.0f) { if (v < s->min_positive) s->min_positive = v; }
-    else if (v == 0.0f) {
-      if (s->zeros.size() < (1u << 26)) s->zeros.push_back(base + i);
-      else s->zeros_overflow = true;
-    }
-  }
+  note_zeros(s, k, plane);
   fseek(s->fp, s->data_offset + (long)(base * 4), SEEK_SET);
   if (fwrite(plane, sizeof(float), n, s->fp) != n) throw Error(-3, "!!ERROR!! short write to " + s->path);
   s->have[k] = 1;
@@ -118,15 +133,8 @@ void mha_write_slice(MhaStack* s, int k, const float* plane) {
 void mha_append(MhaStack* s, const float* plane) {
   if (!s->have.empty()) throw Error(-3, "!!ERROR!! " + s->path + " is written by slice index; append is not allowed");
   if (s->written >= s->nslices) throw Error(-3, "!!ERROR!! more planes appended to " + s->path + " than declared");
-  const size_t n = (size_t)s->nx * s->ny, base = (size_t)s->written * n;
-  for (size_t i = 0; i < n; ++i) {
-    const float v = plane[i];
-    if (v > 0.0f) { if (v < s->min_positive) s->min_positive = v; }
-    else if (v == 0.0f) {
-      if (s->zeros.size() < (1u << 26)) s->zeros.push_back(base + i);
-      else s->zeros_overflow = true;
-    }
-  }
+  const size_t n = (size_t)s->nx * s->ny;
+  note_zeros(s, s->written, plane);
   if (fwrite(plane, sizeof(float), n, s->fp) != n) throw Error(-3, "!!ERROR!! short write to " + s->path);
   s->written++;
 }
@@ -140,19 +148,16 @@ float mha_finish(MhaStack* s, bool replace_zeros) {
     // page-cache copies); a slice with only a handful of zeros gets them patched in place.  The zero positions were
     // recorded while the planes were written.
     const size_t n = (size_t)s->nx * s->ny;
-    const size_t kFewZeros = 64;
-    std::vector<uint32_t> count((size_t)s->nslices, 0);
-    std::vector<size_t> first((size_t)s->nslices + 1, 0);
-    if (!s->zeros_overflow) {
-      if (!s->have.empty()) std::sort(s->zeros.begin(), s->zeros.end());  // slices written by index: any order
-      for (uint64_t idx : s->zeros) ++count[idx / n];
-      for (int k = 0; k < s->nslices; ++k) first[(size_t)k + 1] = first[(size_t)k] + count[k];
-    }
+    if (s->zero_count.empty()) s->zero_count.assign((size_t)s->nslices, 0);
+    const std::vector<uint32_t>& count = s->zero_count;
+    std::vector<size_t> first((size_t)s->nslices + 1, 0);  // positions are recorded for the few-zero slices only
+    std::sort(s->zeros.begin(), s->zeros.end());           // slices written by index arrive in any order
+    for (int k = 0; k < s->nslices; ++k) first[(size_t)k + 1] = first[(size_t)k] + (count[k] <= kFewZeros ? count[k] : 0);
     fflush(s->fp);
     const int fd = fileno(s->fp);
     std::vector<int> dirty;
     for (int k = 0; k < s->nslices; ++k)
-      if (s->zeros_overflow || count[k] > 0) dirty.push_back(k);
+      if (count[k] > 0) dirty.push_back(k);
     const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), dirty.size()}));
     std::vector<int> failed((size_t)nthreads, 0);
     auto work = [&](int t) {
@@ -160,7 +165,7 @@ float mha_finish(MhaStack* s, bool replace_zeros) {
       for (size_t d = (size_t)t; d < dirty.size(); d += (size_t)nthreads) {
         const int k = dirty[d];
         const off_t at = (off_t)(s->data_offset + (long)((size_t)k * n * 4));
-        if (!s->zeros_overflow && count[k] <= kFewZeros) {
+        if (count[k] <= kFewZeros) {
           for (size_t z = first[(size_t)k]; z < first[(size_t)k + 1]; ++z)
             if (pwrite(fd, &fill, 4, (off_t)(s->data_offset + (long)(s->zeros[z] * 4))) != 4) failed[(size_t)t] = 1;
           continue;

@@ -254,8 +254,21 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         if (shared)
           for (int k = 0; k < 3 && wrc == 0; ++k)
             wrc = mcgpu_stack_write_slice(opt->shared_stacks[k], opt->slice_of_projection[sim[i]], planes_host[b] + (size_t)k * plane);
-        else if (opt->write_stacks)
-          for (int k = 0; k < 3 && wrc == 0; ++k) wrc = mcgpu_stack_append(stacks[k], planes_host[b] + (size_t)k * plane);
+        else if (opt->write_stacks) {
+          // the three stacks side by side (each append scans its plane for zeros and copies it into the page cache)
+          int rc3[3] = {0, 0, 0};
+          std::string err3[3];
+          std::thread side[2];
+          for (int k = 1; k < 3; ++k)
+            side[k - 1] = std::thread([&, k] {
+              rc3[k] = mcgpu_stack_append(stacks[k], planes_host[b] + (size_t)k * plane);
+              if (rc3[k] != 0) err3[k] = mcgpu_last_error();  // the last error is per thread
+            });
+          rc3[0] = mcgpu_stack_append(stacks[0], planes_host[b]);
+          for (auto& t : side) t.join();
+          for (int k = 2; k >= 0; --k)
+            if (rc3[k] != 0) { wrc = rc3[k]; if (k > 0) mcgpu_set_last_error_(err3[k].c_str()); }
+        }
         if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, (double)kms[i] * 1e-3, nullptr);
         std::lock_guard<std::mutex> lk(sh.mu);
         sh.writer_s += now_s() - tw0;

@@ -4,6 +4,11 @@ from pathlib import Path
 
 import pytest
 
+try:  # torch (with the ROCm libraries it bundles) must be loaded BEFORE the engine library brings up HIP: loaded after it,
+    import torch  # noqa: F401  -- torch finds no GPU ("No HIP GPUs are available"); some GPU tests hand torch tensors to the engine
+except Exception:  # noqa: BLE001
+    torch = None
+
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
