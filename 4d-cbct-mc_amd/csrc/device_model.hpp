@@ -82,7 +82,7 @@ struct TrackCold {
   // parked histories per wave64 that trigger a batched service of that kind; service everything well populated when
   // fewer lanes than `flyable_low` can fly; stop for a scheduling point once `swap_batch` more lanes have parked
   int thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch;
-  int trade_slots;  // 1: lanes of a wave trade their parking slots at scheduling points (0: MCGPU_NO_SLOT_TRADE, for A/B runs)
+  int trade_slots;  // lanes of a wave trade their parking slots: bit 0 before flying, bit 1 before the Compton and tally/source services (MCGPU_SLOT_TRADE)
 };
 
 struct TrackArgs {

@@ -88,7 +88,7 @@ struct DeviceModel {
   unsigned short* sig_mid = nullptr;  // cross-section brackets (FAST flight step), see upload_model
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
-  int sched[5] = {32, 8, 36, 12, 32};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
+  int sched[5] = {32, 8, 36, 12, 40};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
@@ -879,7 +879,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         TrackCold& ch = D.cold_host;
         const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", D.sched[0]), env_int("MCGPU_THRESH_RAYLEIGH", D.sched[1]), env_int("MCGPU_THRESH_NEW", D.sched[2]),
                               std::max(1, env_int("MCGPU_FLYABLE_LOW", D.sched[3])), std::max(1, env_int("MCGPU_SWAP_BATCH", D.sched[4]))};
-        const int trade = getenv("MCGPU_NO_SLOT_TRADE") ? 0 : 1;
+        const int trade = getenv("MCGPU_SLOT_TRADE") ? atoi(getenv("MCGPU_SLOT_TRADE")) : 3;  // bit 0: before flight, bit 1: before the Compton and tally/source services
         if (ch.trade_slots != trade || ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
             ch.swap_batch != want5[4]) {
           ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];

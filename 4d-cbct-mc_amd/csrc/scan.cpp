@@ -190,7 +190,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     // the environment pins the knobs.
     if (mode == MCGPU_MODE_FAST && total >= 20000000ULL && !getenv("MCGPU_THRESH_COMPTON") && !getenv("MCGPU_THRESH_NEW") &&
         !getenv("MCGPU_SWAP_BATCH") && !getenv("MCGPU_NO_AUTOTUNE")) {
-      static const int presets[3][5] = {{32, 8, 36, 12, 32}, {24, 8, 36, 12, 24}, {28, 8, 40, 12, 36}};
+      static const int presets[3][5] = {{32, 8, 36, 12, 40}, {32, 4, 40, 8, 32}, {24, 8, 36, 12, 24}};
       const unsigned long long probe = 6000000ULL;
       int best = 0;
       float best_ms = 1e30f;

@@ -136,7 +136,7 @@ def cpu_baseline(ctx, seconds_budget: float = 16.0):
 def pmc_summary(workload: str):
     """The committed rocprofv3 PMC summary of the FAST kernel (separate --pmc passes, tools/pmc_collect.sh), accepted only if
     it was collected from THIS kernel build (source hash) on THIS workload; else (None, reason)."""
-    f = ROOT / "profiles" / "pmc_summary_latest.json"
+    f = ROOT / "profiles" / ("pmc_summary_latest.json" if workload == "catphan" else f"pmc_summary_{workload}.json")
     if not f.exists():
         return None, "no summary committed"
     d = json.loads(f.read_text())

@@ -1,0 +1,15 @@
+#!/bin/bash
+# End-of-round measurement set (GPU box, repo root): bench lines, rocprofv3 kernel stats and PMC passes -> gpurun_out/<tag>/
+# Usage: bash tools/collect_round.sh r02
+TAG=${1:-r02}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+for wl in cirs thorax; do python bench.py --workload $wl > $OUT/bench_line_$wl.json 2> $OUT/bench_line_$wl.err; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+head -1 $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/bench_kernel_trace_track.csv; grep track_ $(find $OUT/prof -name "*kernel_trace.csv" | head -1) >> $OUT/bench_kernel_trace_track.csv
+bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json
+bash tools/pmc_collect.sh $OUT/pmc_thorax --workload thorax --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > /dev/null 2>&1; cp $OUT/pmc_thorax/summary.json $OUT/pmc_summary_thorax.json
+BENCH_FORCE_DIST=1 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_line_forced_collective.json 2> $OUT/forced.err
+rm -rf $OUT/prof $OUT/pmc/pass* $OUT/pmc_thorax/pass*
+ls -la $OUT
