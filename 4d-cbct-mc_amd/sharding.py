@@ -21,27 +21,60 @@ def shard_range(units: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi - lo
 
 
-def reduce_image(image, dst: int = 0, narrow: bool = False) -> int:
-    """Sum-reduce a per-rank uint64 tally (held as an int64 torch tensor, any shape) onto rank `dst`, in place there.
-    Returns the payload bytes this rank handed to the collective.
+def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "scatter") -> int:
+    """Sum the per-rank uint64 tallies (held as an int64 torch tensor, any shape) onto rank `dst`, in place there.
+    Returns the payload bytes this rank handed to the collectives.
 
-    `narrow`: send 32-bit words when the SUM provably fits -- the ranks first agree on the largest word anywhere (one
-    8-byte MAX all-reduce, so every rank takes the same branch; a collective with mismatched dtypes would hang), and if
-    `max * world < 2^32` the low words are summed modulo 2^32 (two's-complement add = exact unsigned sum) and widened
-    again on `dst`.  Halves the bytes on the xGMI links; exact either way."""
+    algorithm "scatter" (default) is shaped for xGMI, which is point-to-point -- every GPU has its own link to every other,
+    and a chain/ring reduce to one root pushes the whole tally through single links:
+      1. the tally is cut into `world` slices and slice k of every rank goes straight to rank k (all_to_all_single: all
+         links of the node busy at once, each carrying 1/world of the payload);
+      2. every rank sums the `world` slices it received (one elementwise kernel);
+      3. the summed slices are gathered on `dst` (again one slice per link).
+    Per link that is 2/world of the tally instead of all of it.  algorithm "reduce" is the plain `dist.reduce`.
+
+    `narrow`: 32-bit words on the wire whenever the values provably fit.  The ranks first agree on the largest word anywhere
+    (one 8-byte MAX all-reduce, so every rank takes the same branch; a collective with mismatched dtypes would hang): step 1
+    sends the low words if max < 2^32, step 3 (sums of `world` words) if max * world < 2^32; two's-complement adds of low
+    words are exact unsigned sums.  Integer sums: the result equals the single-GPU tally bit for bit either way."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return 0
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    top = 2 ** 62
     if narrow:
-        top = image.max().reshape(1)
-        dist.all_reduce(top, op=dist.ReduceOp.MAX)
-        if int(top.item()) * world < 2 ** 32:
+        t = image.max().reshape(1)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        top = int(t.item())
+    if algorithm == "reduce":
+        if top * world < 2 ** 32:
             small = image.to(torch.int32)  # keeps the low 32 bits
             dist.reduce(small, dst=dst, op=dist.ReduceOp.SUM)
-            if dist.get_rank() == dst:
+            if rank == dst:
                 image.copy_(small.to(torch.int64) & 0xFFFFFFFF)
             return small.numel() * 4
-    dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
-    return image.numel() * 8
+        dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+        return image.numel() * 8
+    flat = image.view(-1)
+    n = flat.numel()
+    m = (n + world - 1) // world
+    wire1 = torch.int32 if top < 2 ** 32 else torch.int64
+    send = torch.zeros(world * m, dtype=wire1, device=image.device)
+    send[:n] = flat.to(wire1)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    partial = recv.view(world, m).to(torch.int64)
+    if wire1 == torch.int32:
+        partial = partial & 0xFFFFFFFF
+    partial = partial.sum(dim=0)
+    wire2 = torch.int32 if top * world < 2 ** 32 else torch.int64
+    part_w = partial.to(wire2)
+    parts = [torch.empty_like(part_w) for _ in range(world)] if rank == dst else None
+    dist.gather(part_w, parts, dst=dst)
+    if rank == dst:
+        full = torch.cat(parts).to(torch.int64)
+        if wire2 == torch.int32:
+            full = full & 0xFFFFFFFF
+        flat.copy_(full[:n])
+    return send.numel() * send.element_size() + part_w.numel() * part_w.element_size()

@@ -258,9 +258,10 @@ def main():
     t_load = time.perf_counter() - t_load0
 
     nz, nx = ctx.detector_shape
-    # N > 1: every rank tracks its history shard of G consecutive projections into G tally buffers, then ONE RCCL
-    # sum-reduce brings the G tallies to rank 0 (the reference's per-projection MPI_Reduce, MC-GPU_v1.3.cu:1019, batched:
-    # fewer, larger messages over xGMI).  The reduce is ordered between two tracking kernels on purpose: a kernel that is
+    # N > 1: every rank tracks its history shard of G consecutive projections into G tally buffers, then ONE sum-reduction
+    # brings the G tallies to rank 0 (the reference's per-projection MPI_Reduce, MC-GPU_v1.3.cu:1019, batched: fewer, larger
+    # messages; sharding.reduce_image: slices straight to their owners over the point-to-point xGMI links, summed there,
+    # gathered on rank 0).  The reduce is ordered between two tracking kernels on purpose: a kernel that is
     # still running while the persistent tracking grid is dispatched fragments the CUs' register files for the whole
     # launch and costs up to 30 % (tools/placement_probe.py), so nothing overlaps a tracking launch.
     # Payload: 32-bit words whenever the summed tallies provably fit (sharding.reduce_image), else 64-bit.
@@ -272,12 +273,13 @@ def main():
     seed = ctx.geti("seed")
     kernel_ms = []
     narrow = dist is not None and os.environ.get("BENCH_REDUCE_U32", "1") == "1"
+    reduce_algo = os.environ.get("BENCH_REDUCE_ALGO", "scatter")  # sharding.reduce_image: slices to their owners, sum, gather
     reduce_bytes = [0]
 
     def reduce_group():
         if dist and filled[0] > 0:
             # on the current stream: the next tracking launch waits for it (see above)
-            reduce_bytes[0] += cases.pkg.sharding.reduce_image(images[:filled[0]], dst=0, narrow=narrow)
+            reduce_bytes[0] += cases.pkg.sharding.reduce_image(images[:filled[0]], dst=0, narrow=narrow, algorithm=reduce_algo)
         filled[0] = 0
 
     def step(i, timed):
@@ -342,7 +344,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
                        "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
-                       "parallelism": f"history-sharded x{world}" + (f", one RCCL sum-reduce of the detector tallies per {G} projections" if dist else ""),
+                       "parallelism": f"history-sharded x{world}" + (f", one RCCL sum-reduction ({reduce_algo}) of the detector tallies per {G} projections" if dist else ""),
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
                        "volume_bytes": ctx.geti("volume_bytes_device"), "materials_used": ctx.geti("num_materials_used"),
                        "lds_bytes_per_workgroup": ctx.geti("lds_bytes_fast"), "workgroups_per_cu": ctx.geti("blocks_per_cu"),
@@ -360,7 +362,7 @@ def main():
             "check": {"detected_energy_units_last_projection": detected},
         }
         if dist:
-            out["reduce"] = {"bytes_per_rank_in_timed_region": reduce_bytes[0], "narrowed_to_u32": bool(narrow)}
+            out["reduce"] = {"bytes_per_rank_in_timed_region": reduce_bytes[0], "narrowed_to_u32_when_it_fits": bool(narrow), "algorithm": reduce_algo}
         if world == 1:
             if not args.no_compat:
                 out["compat"] = compat_leg(ctx, torch, H)

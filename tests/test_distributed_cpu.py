@@ -30,20 +30,30 @@ def _worker(rank, world, port, input_path, nbatch, hpt, out_path):
         first, count = cases.pkg.sharding.shard_range(nbatch, rank, world)
         img, _ = T.track(0, 42, first, count, hpt, ol.MATH_PORTABLE)
         t = torch.from_numpy(img.view(np.int64).copy())
-        sent = cases.pkg.sharding.reduce_image(t.clone(), dst=0)
-        assert sent == t.numel() * 8
-        # narrowed payload (what bench.py sends when the sums fit 32 bits), and the agreed fallback when they do not:
-        # rank 1 alone holds a word >= 2^31, both ranks must still take the same branch
-        t_narrow = t.clone()
-        assert cases.pkg.sharding.reduce_image(t_narrow, dst=0, narrow=True) == t.numel() * 4
-        big = t.clone()
-        big[0] += (2 ** 31 + 5) * rank
-        assert cases.pkg.sharding.reduce_image(big, dst=0, narrow=True) == t.numel() * 8
-        cases.pkg.sharding.reduce_image(t, dst=0)
+        R = cases.pkg.sharding.reduce_image
+        results = {}
+        for algo in ("scatter", "reduce"):
+            # 64-bit words on the wire
+            x = t.clone()
+            sent = R(x, dst=0, narrow=False, algorithm=algo)
+            assert sent >= t.numel() * 8
+            results[(algo, "wide")] = x
+            # narrowed payload (what bench.py sends when the sums fit 32 bits) ...
+            x = t.clone()
+            assert R(x, dst=0, narrow=True, algorithm=algo) <= t.numel() * 4 * (1 + 1 / world) + 64
+            results[(algo, "narrow")] = x
+            # ... and the agreed fallbacks: rank 1 alone holds a word >= 2^31 (sums no longer fit 32 bits) / >= 2^32 (not
+            # even its own words do): both ranks must still take the same branch
+            for big_word in (2 ** 31 + 5, 2 ** 33 + 7):
+                x = t.clone()
+                x[0] += big_word * rank
+                R(x, dst=0, narrow=True, algorithm=algo)
+                x[0] -= big_word
+                results[(algo, big_word)] = x
+        R(t, dst=0)
         if rank == 0:
-            assert torch.equal(t_narrow, t)
-            big[0] -= 2 ** 31 + 5
-            assert torch.equal(big, t)
+            for key, x in results.items():
+                assert torch.equal(x, t), key
         hist = torch.tensor([count * hpt], dtype=torch.int64)
         dist.reduce(hist, dst=0, op=dist.ReduceOp.SUM)  # exact global history count for the normalisation (MC-GPU_v1.3.cu:878)
         if rank == 0:
