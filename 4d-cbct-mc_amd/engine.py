@@ -64,7 +64,7 @@ def load_library(path: Optional[os.PathLike] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else Path(os.environ.get("MCGPU_ENGINE_LIB") or LIB_PATH)  # the override: A/B runs of two builds on one GPU box
+    p = Path(path) if path else LIB_PATH
     if not p.exists():
         raise ImportError(f"{p} not found: build the HIP engine first (python __graft_entry__.py or make -C 4d-cbct-mc_amd/csrc)")
     lib = C.CDLL(str(p))
