@@ -161,9 +161,11 @@ def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, 
 
 
 @pytest.mark.gpu
-def test_4d_scan_equals_per_state_file_based_runs(engine, tmp_path):
-    """The resident 4-D driver writes, slice for slice, what separate per-state simulations (the reference's flow) give."""
-    g = _slab()
+@pytest.mark.parametrize("phantom", ["slab", "cirs76"])
+def test_4d_scan_equals_per_state_file_based_runs(engine, tmp_path, phantom):
+    """The resident 4-D driver (BASELINE config 5 at reduced size: CIRS phantom + correspondence model + respiratory signal)
+    writes, slice for slice, what separate per-state simulations (the reference's flow) give."""
+    g = _slab() if phantom == "slab" else cases.CASES["cirs76"][0]()
     mats, spc = cases.material_files(), cases.spectrum_file()
     R = cases.pkg.respiratory.RespiratorySignal
     model = _ShiftModel(g.materials.shape)

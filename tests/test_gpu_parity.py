@@ -244,3 +244,25 @@ def test_fast_kernel_tallies_are_pinned(gpu_engine):
 def cases_root():
     from pathlib import Path
     return Path(__file__).resolve().parents[1]
+
+
+def test_fast_kernel_small_and_ragged_history_counts(gpu_engine, case_dir):
+    """History ids are dealt from 64 counters that each own count/64 ids (one more for the first count % 64): launches of 0, 1,
+    63, 64, 65, ... histories simulate exactly that many, every id once -- the tallies of id ranges add up to the whole."""
+    with gpu_engine.create(case_dir("water"), device=0) as ctx:
+        empty, _, done = ctx.run_projection(0, 0, mode="fast", seed=3)
+        assert done == 0 and int(empty.sum()) == 0
+        whole, _, done = ctx.run_projection(0, 1000, mode="fast", seed=3)
+        assert done == 1000 and whole.sum() > 0
+        acc = np.zeros_like(whole)
+        first = 0
+        for n in (1, 63, 64, 65, 2, 128, 300, 377):
+            part, _, d = ctx.run_projection(0, n, mode="fast", seed=3, first=first)
+            assert d == n
+            acc += part
+            first += n
+        assert first == 1000 and np.array_equal(acc, whole)
+        # the same through the asynchronous ABI with the grid of a much larger launch in between (counters are reset per launch)
+        big, _, _ = ctx.run_projection(0, 3_000_000, mode="fast", seed=3)
+        again, _, _ = ctx.run_projection(0, 1000, mode="fast", seed=3)
+        assert np.array_equal(again, whole) and big.sum() > whole.sum()
