@@ -368,7 +368,7 @@ def main():
                 out["compat"] = compat_leg(ctx, torch, H)
             if not args.no_end_to_end:
                 out["end_to_end"] = end_to_end_scan(ctx, H, workdir)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only (the other ranks would idle meanwhile)
             base, img_cpu, w2_cpu, n_cpu = cpu_baseline(ctx)
             out["cpu_baseline"] = base
             # a second ceiling: one scattered 64-bit atomic add per detected photon; rate measured by
