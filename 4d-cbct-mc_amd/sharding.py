@@ -35,8 +35,7 @@ def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "sca
 
     `narrow`: 32-bit words on the wire whenever the values provably fit.  The ranks first agree on the largest word anywhere
     (one 8-byte MAX all-reduce, so every rank takes the same branch; a collective with mismatched dtypes would hang): step 1
-    sends the low words if max < 2^32, step 3 (sums of `world` words) if max * world < 2^32; two's-complement adds of low
-    words are exact unsigned sums.  Integer sums: the result equals the single-GPU tally bit for bit either way."""
+    sends 32-bit words if max < 2^31, step 3 (sums of `world` words, as low words) if max * world < 2^32.  Integer sums: the result equals the single-GPU tally bit for bit either way."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
@@ -48,33 +47,40 @@ def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "sca
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         top = int(t.item())
     if algorithm == "reduce":
-        if top * world < 2 ** 32:
-            small = image.to(torch.int32)  # keeps the low 32 bits
+        if top * world < 2 ** 31:
+            small = image.to(torch.int32)
             dist.reduce(small, dst=dst, op=dist.ReduceOp.SUM)
             if rank == dst:
-                image.copy_(small.to(torch.int64) & 0xFFFFFFFF)
+                image.copy_(small)
             return small.numel() * 4
         dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
         return image.numel() * 8
     flat = image.view(-1)
     n = flat.numel()
     m = (n + world - 1) // world
-    wire1 = torch.int32 if top < 2 ** 32 else torch.int64
-    send = torch.zeros(world * m, dtype=wire1, device=image.device)
-    send[:n] = flat.to(wire1)
-    recv = torch.empty_like(send)
+    # 32-bit words: a rank's own words must stay below 2^31 for step 1 (they are summed as signed numbers), the sums of
+    # `world` of them below 2^32 for step 3 (sent as low words)
+    wire1 = torch.int32 if top < 2 ** 31 else torch.int64
+    wire2 = torch.int32 if top * world < 2 ** 32 else torch.int64  # low words; widened again with a mask on `dst`
+    key = (n, world, str(image.device), wire1, wire2)
+    buf = _BUFFERS.get(key)
+    if buf is None:  # staging buffers are kept: a bench step must not pay allocations and memsets of a few hundred MB
+        _BUFFERS.clear()
+        buf = _BUFFERS[key] = {"send": torch.zeros(world * m, dtype=wire1, device=image.device),
+                               "recv": torch.empty(world * m, dtype=wire1, device=image.device),
+                               "full": torch.empty(world * m, dtype=wire2, device=image.device) if rank == dst else None}
+    send, recv = buf["send"], buf["recv"]
+    send[:n].copy_(flat)  # narrowing copy (the tail beyond n stays zero)
     dist.all_to_all_single(recv, send)
-    partial = recv.view(world, m).to(torch.int64)
-    if wire1 == torch.int32:
-        partial = partial & 0xFFFFFFFF
-    partial = partial.sum(dim=0)
-    wire2 = torch.int32 if top * world < 2 ** 32 else torch.int64
-    part_w = partial.to(wire2)
-    parts = [torch.empty_like(part_w) for _ in range(world)] if rank == dst else None
+    part = recv.view(world, m).sum(dim=0, dtype=torch.int64)
+    part_w = part if wire2 == torch.int64 else part.to(torch.int32)  # keeps the low 32 bits
+    parts = list(buf["full"].view(world, m).unbind(0)) if rank == dst else None
     dist.gather(part_w, parts, dst=dst)
     if rank == dst:
-        full = torch.cat(parts).to(torch.int64)
+        flat.copy_(buf["full"][:n])  # widening copy (sign-extends)
         if wire2 == torch.int32:
-            full = full & 0xFFFFFFFF
-        flat.copy_(full[:n])
+            flat.bitwise_and_(0xFFFFFFFF)
     return send.numel() * send.element_size() + part_w.numel() * part_w.element_size()
+
+
+_BUFFERS: dict = {}

@@ -44,7 +44,7 @@ def _worker(rank, world, port, input_path, nbatch, hpt, out_path):
             results[(algo, "narrow")] = x
             # ... and the agreed fallbacks: rank 1 alone holds a word >= 2^31 (sums no longer fit 32 bits) / >= 2^32 (not
             # even its own words do): both ranks must still take the same branch
-            for big_word in (2 ** 31 + 5, 2 ** 33 + 7):
+            for big_word in (2 ** 30 + 5, 2 ** 31 + 5, 2 ** 33 + 7):
                 x = t.clone()
                 x[0] += big_word * rank
                 R(x, dst=0, narrow=True, algorithm=algo)
