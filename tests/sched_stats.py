@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cases
 eng = cases.pkg.engine
-inp = sys.argv[1] if len(sys.argv) > 1 else "/tmp/mcgpu_bench_512_894/input.in"
+inp = sys.argv[1] if len(sys.argv) > 1 else "/tmp/mcgpu_bench_catphan_512_894/input.in"
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
 configs = sys.argv[3:] or [""]
 KEYS = ("MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH")

@@ -21,7 +21,7 @@ eng._lib = lib
 n = int(float(sys.argv[3])) if len(sys.argv) > 3 else 3_000_000
 projs = [int(a) for a in sys.argv[4:]] or [300]
 out = {}
-with eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0) as ctx:
+with eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0) as ctx:
     for p in projs:
         img, secs, done = ctx.run_projection(p, n, mode="fast", seed=42)
         out[f"p{p}"] = img

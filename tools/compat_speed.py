@@ -2,7 +2,7 @@ import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import cases
 eng = cases.pkg.engine
-with eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0) as ctx:
+with eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0) as ctx:
     for mode in ("compat", "fast"):
         ctx.run_projection(0, int(2e7), mode=mode, seed=42)
         _, secs, done = ctx.run_projection(0, int(1e8), mode=mode, seed=42)

@@ -2,7 +2,7 @@ import sys, hashlib, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import cases
 eng = cases.pkg.engine
-with eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0) as ctx:
+with eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0) as ctx:
     hs = []
     for k in range(4):
         img, secs, done = ctx.run_projection(200, 60_000_000, mode="fast", seed=42)

@@ -15,7 +15,7 @@ for name, n in [("air", 100_000), ("water", 300_000), ("catphan64", 400_000), ("
         for p in range(ctx.num_projections):
             img, secs, done = ctx.run_projection(p, n, mode="fast", seed=42 + p)
             out[f"{name}:{p}"] = hashlib.sha256(img.tobytes()).hexdigest()[:16] + f":{int(img.sum())}"
-bench = Path("/tmp/mcgpu_bench_512_894/input.in")
+bench = Path("/tmp/mcgpu_bench_catphan_512_894/input.in")
 if bench.exists():
     with eng.create(bench, device=0) as ctx:
         for p in (0, 300):

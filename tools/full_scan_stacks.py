@@ -5,7 +5,7 @@ import cases
 from pathlib import Path
 eng = cases.pkg.engine
 out = Path("/tmp/scan_full_stacks"); out.mkdir(exist_ok=True)
-with eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0) as ctx:
+with eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0) as ctx:
     t0 = time.time()
     r = ctx.run_scan(mode="fast", histories=int(1e8), crop_nx=1024, write_stacks=True, output_folder=out, pixel_spacing=(0.776, 0.776))
     print({k: round(v, 3) if isinstance(v, float) else v for k, v in r.items() if k != "zero_replacement"}, "wall", round(time.time() - t0, 2))

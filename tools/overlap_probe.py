@@ -4,7 +4,7 @@ import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch, cases
 eng = cases.pkg.engine
-ctx = eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0)
+ctx = eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0)
 nz, nx = ctx.detector_shape
 image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
 side = torch.cuda.Stream()

@@ -6,7 +6,7 @@ from pathlib import Path
 eng = cases.pkg.engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 out = Path("/tmp/scan_ascii"); out.mkdir(exist_ok=True)
-with eng.create("/tmp/mcgpu_bench_512_894/input.in", device=0) as ctx:
+with eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0) as ctx:
     t0 = time.time()
     r = ctx.run_scan(mode="fast", first_projection=0, num_projections=n, histories=int(1e8), crop_nx=1024, write_ascii=True, write_stacks=False, output_folder=out)
     print({k: round(v, 3) if isinstance(v, float) else v for k, v in r.items() if k != "zero_replacement"},

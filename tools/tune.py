@@ -5,7 +5,7 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch, cases
 eng = cases.pkg.engine
 KEYS = ("MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH")
-ctx = eng.create(os.environ.get("TUNE_INPUT", "/tmp/mcgpu_bench_512_894/input.in"), device=0)
+ctx = eng.create(os.environ.get("TUNE_INPUT", "/tmp/mcgpu_bench_catphan_512_894/input.in"), device=0)
 nz, nx = ctx.detector_shape
 image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
