@@ -17,6 +17,7 @@
 
 #include "../../include/mcgpu_amd.h"
 #include "device_model.hpp"
+#include "ascii_device.hpp"
 #include "geometry_device.hpp"
 
 namespace mcgpu {
@@ -53,6 +54,16 @@ struct DeviceModel {
   int vol_kind = kVolU8, palette_size = 0;
   float* palette = nullptr;
   unsigned char* bricks = nullptr;
+  // on-device formatter of the ASCII projection files (mcgpu_format_projection): two slots, so that the host writes one
+  // projection's text while the next is formatted
+  struct AsciiSlot {
+    char* text_dev = nullptr;
+    char* text_host = nullptr;            // pinned
+    unsigned long long* rows_dev = nullptr;   // row_len[nz] row_off[nz+1] row_arg[nz] | row_sum[nz] row_max[nz] | flags
+    unsigned long long* rows_host = nullptr;  // pinned copy of the same block
+  } ascii[2];
+  unsigned long long ascii_capacity = 0;
+  hipStream_t copy_stream = nullptr;
   // on-device geometry changes (mcgpu_warp_geometry): the base geometry's palette index volume, scratch, the palette on the
   // host and the code assignment of the base geometry
   unsigned char* vol_base = nullptr;
@@ -117,6 +128,13 @@ struct DeviceModel {
   void release() {
     for (void* p : allocations) (void)hipFree(p);
     allocations.clear();
+    for (AsciiSlot& a : ascii) {
+      if (a.text_host) (void)hipHostFree(a.text_host);
+      if (a.rows_host) (void)hipHostFree(a.rows_host);
+      a = AsciiSlot();
+    }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
     ev_start = ev_stop = nullptr;
@@ -986,6 +1004,82 @@ int mcgpu_write_projection(mcgpu_ctx* ctx, int p, const uint64_t* image_host, un
   require(total_histories > 0, -2, "!!ERROR!! mcgpu_write_projection: zero histories");
   const std::string name = file_name ? std::string(file_name) : projection_file_name(ctx->host, p);
   write_projection_ascii(ctx->host, p, image_host, total_histories, seconds, name);
+  return 0;
+  ABI_END
+}
+
+// Layout of an AsciiSlot's row block in 8-byte words: row_len[nz], row_off[nz + 1], row_arg[nz], row_sum[nz] (double),
+// row_max[nz] (double), flags
+static size_t ascii_row_words(int nz) { return (size_t)5 * nz + 2; }
+
+int mcgpu_format_projection(mcgpu_ctx* ctx, const void* image_dev, unsigned long long total_histories, int slot, void* hip_stream) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && image_dev && (slot == 0 || slot == 1) && total_histories > 0, -1, "!!ERROR!! mcgpu_format_projection: bad argument");
+  DeviceModel& D = ctx->dev;
+  HIP_TRY(hipSetDevice(D.device_id));
+  const DetectorPose& d0 = ctx->host.detector[0];
+  const int nx = d0.nx, nz = d0.nz;
+  const size_t npix = (size_t)nx * nz, words = ascii_row_words(nz);
+  DeviceModel::AsciiSlot& S = D.ascii[slot];
+  if (!S.text_dev) {
+    // room for 11 integer digits per number (values below 1e11 eV/cm^2 per history; a tally of 1e8 125-keV photons in one
+    // 0.04 cm pixel would be 3e5): the formatter flags a projection that needs more
+    D.ascii_capacity = npix * (4 * (11 + 9) + 4) + (size_t)nz + 64;
+    void* t = nullptr;
+    HIP_TRY(hipMalloc(&t, D.ascii_capacity));
+    D.allocations.push_back(t);  // freed by release()
+    S.text_dev = (char*)t;
+    S.rows_dev = D.put(std::vector<unsigned long long>(words, 0ULL));
+    HIP_TRY(hipHostMalloc((void**)&S.text_host, D.ascii_capacity, hipHostMallocNonCoherent));
+    HIP_TRY(hipHostMalloc((void**)&S.rows_host, words * 8, hipHostMallocDefault));
+    if (!D.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking));
+  }
+  AsciiArgs a;
+  a.image = (const unsigned long long*)image_dev;
+  a.nx = nx; a.nz = nz; a.npix = npix;
+  a.norm = projection_norm(ctx->host, total_histories);
+  a.text = S.text_dev; a.capacity = D.ascii_capacity;
+  a.row_len = S.rows_dev; a.row_off = S.rows_dev + nz; a.row_arg = (long long*)(S.rows_dev + 2 * nz + 1);
+  a.row_sum = (double*)(S.rows_dev + 3 * nz + 1); a.row_max = (double*)(S.rows_dev + 4 * nz + 1);
+  a.flags = (unsigned int*)(S.rows_dev + 5 * nz + 1);
+  HIP_TRY(launch_ascii_format(a, (hipStream_t)hip_stream));
+  HIP_TRY(hipMemcpyAsync(S.rows_host, S.rows_dev, words * 8, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  return 0;
+  ABI_END
+}
+
+int mcgpu_write_formatted_projection(mcgpu_ctx* ctx, int p, int slot, unsigned long long total_histories, double seconds, const char* file_name) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && (slot == 0 || slot == 1) && p >= 0 && p < ctx->host.cfg.num_projections && total_histories > 0, -1,
+          "!!ERROR!! mcgpu_write_formatted_projection: bad argument");
+  DeviceModel& D = ctx->dev;
+  DeviceModel::AsciiSlot& S = D.ascii[slot];
+  require(S.text_dev != nullptr, -1, "!!ERROR!! mcgpu_write_formatted_projection: nothing was formatted in this slot");
+  HIP_TRY(hipSetDevice(D.device_id));
+  const int nz = ctx->host.detector[0].nz;
+  const unsigned long long* rows = S.rows_host;
+  const unsigned int flags = (unsigned int)rows[5 * nz + 1];
+  require(flags == 0u, -3, "!!ERROR!! projection values outside the range of the device formatter (>= 1e11 eV/cm^2 per history)");
+  const size_t bytes = (size_t)rows[2 * nz];  // row_off[nz]
+  const auto t_a = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemcpyAsync(S.text_host, S.text_dev, bytes, hipMemcpyDeviceToHost, D.copy_stream));
+  HIP_TRY(hipStreamSynchronize(D.copy_stream));
+  const auto t_b = std::chrono::steady_clock::now();
+  // footer inputs: the rows in order (the first of equal maxima wins, MC-GPU_v1.3.cu:2893-2897)
+  const long long* arg = (const long long*)(rows + 2 * nz + 1);
+  const double* sum = (const double*)(rows + 3 * nz + 1);
+  const double* mx = (const double*)(rows + 4 * nz + 1);
+  double integral = 0.0, maximum = -100.0;
+  long max_pixel = 0;
+  for (int z = 0; z < nz; ++z) {
+    integral += sum[z];
+    if (mx[z] > maximum) { maximum = mx[z]; max_pixel = (long)arg[z]; }
+  }
+  const std::string name = file_name ? std::string(file_name) : projection_file_name(ctx->host, p);
+  write_projection_preformatted(ctx->host, p, S.text_host, bytes, integral, maximum, max_pixel, total_histories, seconds, name);
+  if (getenv("MCGPU_ASCII_TIMING"))
+    fprintf(stderr, "ascii: %zu bytes, download %.2f ms, file %.2f ms\n", bytes, std::chrono::duration<double, std::milli>(t_b - t_a).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
   return 0;
   ABI_END
 }

@@ -139,6 +139,12 @@ std::string projection_file_name(const HostModel& m, int p);
 size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, unsigned long long total_histories,
                               double seconds, const std::string& file_name, int n_threads = 0);
 
+// The same file from data lines formatted elsewhere (ascii_device.hip): NORM of the pixel values, and the writer
+double projection_norm(const HostModel& m, unsigned long long total_histories);
+size_t write_projection_preformatted(const HostModel& m, int p, const char* text, size_t text_bytes, double energy_integral, double maximum,
+                                     long max_pixel, unsigned long long total_histories, double seconds, const std::string& file_name,
+                                     int n_threads = 0);
+
 // Dose reports (report_voxels_dose :2976-3199, report_materials_dose :3214-3262, material masses :579-585); the text the
 // reference prints to stdout is appended to `log`.
 void material_masses(const HostModel& m, double mass[kMaxMaterials]);

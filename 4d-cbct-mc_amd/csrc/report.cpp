@@ -77,12 +77,18 @@ std::string projection_file_name(const HostModel& m, int p) {
   return buf;
 }
 
-size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, unsigned long long total_histories,
-                              double seconds, const std::string& file_name, int n_threads) {
+namespace {
+auto appendf = [](std::string& to, const char* fmt, auto... args) {
+  char line[1024];
+  const int k = snprintf(line, sizeof line, fmt, args...);
+  to.append(line, (size_t)std::min<int>(std::max(k, 0), (int)sizeof line - 1));
+};
+
+// the 20 comment lines in front of the data (report_image, MC-GPU_v1.3.cu:2818-2858)
+std::string projection_header(const HostModel& m, int p) {
   const SimConfig& c = m.cfg;
   const DetectorPose& d0 = m.detector[0];
   const int nx = d0.nx, nz = d0.nz;
-  const size_t npix = (size_t)nx * nz;
   float cur, seq;
   if (c.enable_specific_angles == 0) {
     cur = (float)rad2deg(c.initial_angle + p * c.D_angle);
@@ -92,17 +98,7 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
     cur = c.specific_angles[p];
     seq = cur;
   }
-  // No stdio stream and no shared buffer: header, bands and footer are formatted into memory owned by this call and
-  // written at their offsets with pwrite, so concurrent calls (one scan per GPU in one process) cannot interleave.
-  const int fd = open(file_name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-  if (fd < 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " can not be opened!!");
-  struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) close(fd); } } closer{fd};
-  std::string header, footer;
-  auto appendf = [](std::string& to, const char* fmt, auto... args) {
-    char line[1024];
-    const int k = snprintf(line, sizeof line, fmt, args...);
-    to.append(line, (size_t)std::min<int>(std::max(k, 0), (int)sizeof line - 1));
-  };
+  std::string header;
   const SourcePose& s = m.source[p];
   header += "# \n";
   header += "#     *****************************************************************************\n";
@@ -128,6 +124,88 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
   header += "#  [NON-SCATTERED] [COMPTON] [RAYLEIGH] [MULTIPLE-SCATTING]\n";
   header += "# ==========================================================\n";
 
+  return header;
+}
+
+// the comment lines behind the data (:2906-2947)
+std::string projection_footer(const HostModel& m, double energy_integral, double maximum, long max_pixel, unsigned long long total_histories,
+                              double seconds) {
+  const DetectorPose& d0 = m.detector[0];
+  const int nx = d0.nx;
+  const double SCALE = 1.0 / 100.0f;  // 1/SCALE_eV (MC-GPU_v1.3.cu:2860)
+  const double NORM = SCALE * d0.inv_pixel_size_X * d0.inv_pixel_size_Z / ((double)total_histories);
+  std::string footer;
+  footer += "#   *** Simulation REPORT: ***\n";
+  appendf(footer, "#       Fraction of energy detected (over the mean energy of the spectrum): %.3lf%%\n",
+                   100.0 * SCALE * (energy_integral / (double)total_histories) / (double)m.spectrum.mean_energy);
+  appendf(footer, "#       Maximum energy detected in pixel %i: (x,y)=(%i,%i) -> pixel value = %lf eV/cm^2\n", (int)max_pixel,
+                   (int)(max_pixel % nx), (int)(max_pixel / nx), NORM * maximum);
+  appendf(footer, "#       Simulated x rays:    %lld\n", (long long)total_histories);
+  appendf(footer, "#       Simulation time [s]: %.2f\n", seconds);
+  if (seconds > 0.000001) appendf(footer, "#       Speed [x-rays/sec]:  %.2f\n\n", ((double)total_histories) / seconds);
+  return footer;
+}
+
+bool pwrite_all(int fd, const char* data, size_t len, off_t where) {
+  size_t done = 0;
+  while (done < len) {
+    const ssize_t k = pwrite(fd, data + done, len - done, where + (off_t)done);
+    if (k <= 0) return false;
+    done += (size_t)k;
+  }
+  return true;
+}
+}  // namespace
+
+double projection_norm(const HostModel& m, unsigned long long total_histories) {
+  const DetectorPose& d0 = m.detector[0];
+  const double SCALE = 1.0 / 100.0f;
+  return SCALE * d0.inv_pixel_size_X * d0.inv_pixel_size_Z / ((double)total_histories);
+}
+
+// A projection file whose data lines were formatted elsewhere (on the device: ascii_device.hip): header, the text as it is,
+// footer; the text goes to the file in parallel slices at their offsets.
+size_t write_projection_preformatted(const HostModel& m, int p, const char* text, size_t text_bytes, double energy_integral, double maximum,
+                                     long max_pixel, unsigned long long total_histories, double seconds, const std::string& file_name,
+                                     int n_threads) {
+  const int fd = open(file_name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " can not be opened!!");
+  struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) close(fd); } } closer{fd};
+  const std::string header = projection_header(m, p), footer = projection_footer(m, energy_integral, maximum, max_pixel, total_histories, seconds);
+  const size_t total = header.size() + text_bytes + footer.size();
+  // ONE thread per file: concurrent write()s to one file serialise on its inode lock (measured per 63 MB file: 1 thread 7 ms,
+  // 2-16 threads 16-20 ms; a shared mapping filled by 16 threads 40 ms).  Parallelism comes from writing two files at a time
+  // (scan.cpp: one worker per formatter slot).
+  int T = n_threads > 0 ? n_threads : 1;
+  std::vector<int> bad((size_t)T, 0);
+  auto put = [&](int t) {
+    const size_t b0 = text_bytes * (size_t)t / (size_t)T, b1 = text_bytes * ((size_t)t + 1) / (size_t)T;
+    bad[(size_t)t] = !pwrite_all(fd, text + b0, b1 - b0, (off_t)(header.size() + b0));
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(put, t);
+  bool ok = pwrite_all(fd, header.data(), header.size(), 0);
+  put(0);
+  for (auto& x : th) x.join();
+  for (int t = 0; t < T; ++t) ok = ok && !bad[(size_t)t];
+  ok = ok && pwrite_all(fd, footer.data(), footer.size(), (off_t)(header.size() + text_bytes));
+  closer.fd = -1;
+  if (close(fd) != 0 || !ok) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " could not be written!!");
+  return total;
+}
+
+size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, unsigned long long total_histories,
+                              double seconds, const std::string& file_name, int n_threads) {
+  const DetectorPose& d0 = m.detector[0];
+  const int nx = d0.nx, nz = d0.nz;
+  const size_t npix = (size_t)nx * nz;
+  // No stdio stream and no shared buffer: header, bands and footer are formatted into memory owned by this call and
+  // written at their offsets with pwrite, so concurrent calls (one scan per GPU in one process) cannot interleave.
+  const int fd = open(file_name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) throw Error(-3, "!!fopen ERROR report_image!! File " + file_name + " can not be opened!!");
+  struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) close(fd); } } closer{fd};
+  const std::string header = projection_header(m, p);
+  std::string footer;
   const double SCALE = 1.0 / 100.0f;  // 1/SCALE_eV (MC-GPU_v1.3.cu:2860)
   const double NORM = SCALE * d0.inv_pixel_size_X * d0.inv_pixel_size_Z / ((double)total_histories);
 
@@ -229,14 +307,7 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
     energy_integral += integral[t];  // NB: summed per band; the footer's %.3lf is insensitive to the order
     if (maxval[t] > maximum) { maximum = maxval[t]; max_pixel = maxpix[t]; }
   }
-  footer += "#   *** Simulation REPORT: ***\n";
-  appendf(footer, "#       Fraction of energy detected (over the mean energy of the spectrum): %.3lf%%\n",
-                   100.0 * SCALE * (energy_integral / (double)total_histories) / (double)m.spectrum.mean_energy);
-  appendf(footer, "#       Maximum energy detected in pixel %i: (x,y)=(%i,%i) -> pixel value = %lf eV/cm^2\n", (int)max_pixel,
-                   (int)(max_pixel % nx), (int)(max_pixel / nx), NORM * maximum);
-  appendf(footer, "#       Simulated x rays:    %lld\n", (long long)total_histories);
-  appendf(footer, "#       Simulation time [s]: %.2f\n", seconds);
-  if (seconds > 0.000001) appendf(footer, "#       Speed [x-rays/sec]:  %.2f\n\n", ((double)total_histories) / seconds);
+  footer = projection_footer(m, energy_integral, maximum, max_pixel, total_histories, seconds);
   {
     size_t done = 0;
     while (done < footer.size()) {

@@ -85,7 +85,14 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     bool abort = false;
     std::string error;
     double writer_s = 0.0;
+    // ASCII files of the device formatter: one worker per slot, so that two files are written side by side (writes to
+    // ONE file do not scale with threads -- they serialise on its inode lock -- writes to two files do)
+    bool ascii_busy[2] = {false, false};
+    int ascii_p[2] = {0, 0};
+    double ascii_seconds[2] = {0.0, 0.0};
+    bool ascii_quit = false;
   } sh;
+  std::thread ascii_worker[2];
   mcgpu_ctx* ctx = ctxs[0];
   int rc = 0;
   try {
@@ -147,6 +154,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
 
     // ---- device resources
     const unsigned int pinned_flags = getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent;
+    const bool ascii_on_host = getenv("MCGPU_ASCII_HOST") != nullptr;  // A/B: the threaded host formatter of report.cpp
     const bool single = (n_ctx == 1);
     for (int g = 0; g < n_ctx; ++g) {
       HIP_OK(hipSetDevice(D[g].dev));
@@ -220,7 +228,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));
       // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte (ordering: see the event below)
       HIP_OK(hipHostMalloc((void**)&planes_host[b], 3 * plane * 4, pinned_flags));
-      if (opt->write_ascii) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, pinned_flags));
+      if (opt->write_ascii && ascii_on_host) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, pinned_flags));
       // the writer thread reads non-coherent pinned memory after waiting on this event: that needs a SYSTEM-scope release,
       // which a default event does not promise (device scope only)
       HIP_OK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming | hipEventReleaseToSystem));
@@ -233,6 +241,30 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     }
 
     std::vector<float> kms(count, 0.f);  // kernel time per projection (written before the projection is queued)
+    const bool ascii_async = opt->write_ascii && !ascii_on_host;
+    if (ascii_async)
+      for (int b = 0; b < 2; ++b)
+        ascii_worker[b] = std::thread([&, b]() {
+          for (;;) {
+            int p;
+            double secs;
+            {
+              std::unique_lock<std::mutex> lk(sh.mu);
+              sh.cv.wait(lk, [&] { return sh.ascii_busy[b] || sh.ascii_quit || sh.abort; });
+              if (!sh.ascii_busy[b]) return;
+              p = sh.ascii_p[b];
+              secs = sh.ascii_seconds[b];
+            }
+            const double tw0 = now_s();
+            const int wrc = mcgpu_write_formatted_projection(ctx, p, b, total, secs, nullptr);
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.writer_s += now_s() - tw0;
+            if (wrc != 0) { sh.error = mcgpu_last_error(); sh.abort = true; }
+            sh.ascii_busy[b] = false;
+            sh.cv.notify_all();
+            if (wrc != 0) return;
+          }
+        });
     // ---- writer thread: consumes buffers in order
     writer = std::thread([&]() {
       for (int i = 0; i < count; ++i) {
@@ -269,8 +301,13 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
           for (int k = 2; k >= 0; --k)
             if (rc3[k] != 0) { wrc = rc3[k]; if (k > 0) mcgpu_set_last_error_(err3[k].c_str()); }
         }
-        if (wrc == 0 && opt->write_ascii) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, (double)kms[i] * 1e-3, nullptr);
+        if (wrc == 0 && opt->write_ascii && ascii_on_host) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, (double)kms[i] * 1e-3, nullptr);
         std::lock_guard<std::mutex> lk(sh.mu);
+        if (wrc == 0 && ascii_async) {  // slot b is free: the projection loop waited for that before it formatted into it
+          sh.ascii_p[b] = p;
+          sh.ascii_seconds[b] = (double)kms[i] * 1e-3;
+          sh.ascii_busy[b] = true;
+        }
         sh.writer_s += now_s() - tw0;
         if (wrc != 0) { sh.error = mcgpu_last_error(); sh.abort = true; }
         sh.written = i + 1;
@@ -291,7 +328,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       const int b = j & 1, t = single ? 0 : b;
       {  // pinned buffer b is free once projection j-2 has been written
         std::unique_lock<std::mutex> lk(sh.mu);
-        sh.cv.wait(lk, [&] { return sh.written >= j - 1 || sh.abort; });
+        sh.cv.wait(lk, [&] { return (sh.written >= j - 1 && !sh.ascii_busy[b]) || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
       HIP_OK(hipSetDevice(D[0].dev));
@@ -300,7 +337,12 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         HIP_OK(mcgpu::launch_accumulate((unsigned long long*)D[0].image[t], (const unsigned long long*)D[g].landing[b], words, s0));
       }
       if (!single) HIP_OK(hipEventRecord(consumed[b], s0));
-      if (opt->write_ascii) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, s0));
+      // the reference's ASCII file: its 63 MB of text are formatted on the device (ascii_device.hip) before the tally is
+      // cleared; the writer thread downloads and writes them while the next projection is tracked
+      if (opt->write_ascii) {
+        if (ascii_on_host) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, s0));
+        else ABI_OK(mcgpu_format_projection(ctx, D[0].image[t], total, b, s0));
+      }
       ABI_OK(mcgpu_finalize_projection(ctx, D[0].image[t], total, cx, planes_dev[b], 1, s0));
       HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, s0));
       HIP_OK(hipEventRecord(done[b], s0));
@@ -355,6 +397,14 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     if (!single && count > 0) { enqueue_reduce(count - 1); publish(count - 1); }
     writer.join();
     {
+      std::unique_lock<std::mutex> lk(sh.mu);
+      sh.cv.wait(lk, [&] { return (!sh.ascii_busy[0] && !sh.ascii_busy[1]) || sh.abort; });
+      sh.ascii_quit = true;
+      sh.cv.notify_all();
+    }
+    for (auto& w : ascii_worker)
+      if (w.joinable()) w.join();
+    {
       std::lock_guard<std::mutex> lk(sh.mu);
       if (sh.abort) throw ScanError{-3, sh.error};
     }
@@ -387,6 +437,8 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       sh.cv.notify_all();
     }
     if (writer.joinable()) writer.join();
+    for (auto& w : ascii_worker)
+      if (w.joinable()) w.join();
   }
   for (int k = 0; k < 3; ++k)
     if (stacks[k]) (void)mcgpu_stack_finish(stacks[k], 0, nullptr);  // error path: close the files

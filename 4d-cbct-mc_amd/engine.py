@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_clone", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
-    "mcgpu_write_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
+    "mcgpu_write_projection", "mcgpu_format_projection", "mcgpu_write_formatted_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
@@ -91,6 +91,8 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_clear_image.argtypes = [vp, vp, vp]
     lib.mcgpu_run_projection.argtypes = [vp, ci, ci, ci, cull, cull, ci, vp, C.POINTER(C.c_double), C.POINTER(cull)]
     lib.mcgpu_write_projection.argtypes = [vp, ci, vp, cull, C.c_double, cp]
+    lib.mcgpu_format_projection.argtypes = [vp, vp, cull, ci, vp]
+    lib.mcgpu_write_formatted_projection.argtypes = [vp, ci, ci, cull, C.c_double, cp]
     lib.mcgpu_dose_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_size_t)]
     lib.mcgpu_dose_read.argtypes = [vp, vp, vp]
     lib.mcgpu_dose_clear.argtypes = [vp]
@@ -326,6 +328,16 @@ class Context:
         assert img.size == self.image_words
         _check(self.lib.mcgpu_write_projection(self.h, p, img.ctypes.data, int(total_histories), float(seconds),
                                                file_name.encode() if file_name else None))
+        return file_name or self.projection_file_name(p)
+
+    def write_projection_device(self, p: int, image_dev_ptr: int, total_histories: int, seconds: float = 0.0, file_name: Optional[str] = None,
+                                slot: int = 0, stream: int = 0):
+        """The same file with the data lines formatted on the device from a device tally (mcgpu_format_projection +
+        mcgpu_write_formatted_projection); synchronises `stream` in between."""
+        _check(self.lib.mcgpu_format_projection(self.h, C.c_void_p(image_dev_ptr), int(total_histories), int(slot), C.c_void_p(stream)))
+        import torch
+        torch.cuda.synchronize()
+        _check(self.lib.mcgpu_write_formatted_projection(self.h, p, int(slot), int(total_histories), float(seconds), file_name.encode() if file_name else None))
         return file_name or self.projection_file_name(p)
 
     # -- post-processing (cbctmc/mc/projection.py) and the whole-scan pipeline

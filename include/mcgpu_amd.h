@@ -119,6 +119,16 @@ int mcgpu_run_projection(mcgpu_ctx *ctx, int p, int mode, int seed, unsigned lon
 int mcgpu_write_projection(mcgpu_ctx *ctx, int p, const uint64_t *image_host, unsigned long long total_histories, double seconds,
                            const char *file_name);
 
+/* report_image with the 1.4 M data lines formatted ON THE DEVICE (MC-GPU_v1.3.cu:2860-2904: four "%.8lf" numbers per pixel,
+ * a blank line per detector row; exact decimal conversion in integer arithmetic, byte-identical to mcgpu_write_projection).
+ * mcgpu_format_projection is asynchronous on `hip_stream`: it reads the device tally `image_dev` (before it is cleared) and
+ * fills one of two internal slots; once the stream has passed that point (event / synchronize), the host side
+ * mcgpu_write_formatted_projection downloads the text with a copy engine and writes header + text + footer.  The scan driver
+ * alternates the slots, so the file of projection i is written while i + 1 is tracked and formatted. */
+int mcgpu_format_projection(mcgpu_ctx *ctx, const void *image_dev, unsigned long long total_histories, int slot, void *hip_stream);
+int mcgpu_write_formatted_projection(mcgpu_ctx *ctx, int p, int slot, unsigned long long total_histories, double seconds,
+                                     const char *file_name);
+
 /* Dose tallies (tally_materials_dose MC-GPU_kernel_v1.3.cu:1547-1563, tally_voxel_energy_deposition :418-443; enabled by
  * SECTION DOSE DEPOSITION of the input file, MC-GPU_v1.3.cu:1619-1709).  The context owns device buffers that every
  * launch adds into (all projections accumulate, as in the reference).

@@ -214,3 +214,33 @@ def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_
                 c.close()
         res.append(engine.stack_read(out / "projections_total.mha"))
     assert np.array_equal(res[0], res[1])
+
+
+@pytest.mark.gpu
+def test_device_formatted_projection_file_is_byte_identical(engine, case_dir, tmp_path):
+    """The data lines formatted on the device ("%.8lf" by exact integer arithmetic, ascii_device.hip) against the host writer
+    (itself byte-identical to the reference's report_image on the data lines): random tallies over many magnitudes, zeros, the
+    largest words, and values that land exactly on a rounding tie."""
+    import torch
+    rng = np.random.default_rng(11)
+    with engine.create(case_dir("catphan64_ct"), device=0) as ctx:
+        nz, nx = ctx.detector_shape
+        for k, n_hist in enumerate((1_000_000, 3, 2 ** 20, 123_456_789)):
+            norm = 0.01 * (10.0 / ctx.getf("pixel_size_x_mm")) * (10.0 / ctx.getf("pixel_size_z_mm")) / n_hist
+            top = int(np.log2(5.0e9 / norm))  # values up to 5e9 eV/cm^2 per history: 10 integer digits (physical ones have <= 6)
+            img = np.zeros((4, nz, nx), dtype=np.uint64)
+            mag = rng.integers(0, top, size=img.shape)
+            img[:] = (rng.random(img.shape) * (2.0 ** mag)).astype(np.uint64)
+            img[rng.random(img.shape) < 0.3] = 0
+            img[0, 0, :6] = [0, 1, 2, 5, 2 ** (top - 1), 2 ** top - 1]
+            if n_hist == 2 ** 20:
+                # many products NORM * e * 1e8 with short binary fractions (ties and near-ties of the 8th digit among them)
+                img[1, 1, :] = np.arange(nx, dtype=np.uint64) * 5 + 1
+                img[2, 2, :] = (np.arange(nx, dtype=np.uint64) + 1) * 2 ** 19
+            dev = torch.from_numpy(img.view(np.int64)).cuda()
+            want = tmp_path / f"host_{k}"
+            got = tmp_path / f"device_{k}"
+            ctx.write_projection(1, img, n_hist, 2.5, file_name=str(want))
+            ctx.write_projection_device(1, dev.data_ptr(), n_hist, 2.5, file_name=str(got), slot=k & 1)
+            a, b = want.read_bytes(), got.read_bytes()
+            assert len(a) == len(b) and a == b, (k, len(a), len(b))
