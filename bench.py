@@ -42,14 +42,19 @@ WORKLOADS = {
     "cirs": ("cirs_305x300x152_1mm_insert", 149.0, "SURVEY 8d: 8x8.76 + 24x2.12 + 8x1.72 + 16x0.90"),
     "thorax": ("thorax_like_512x512x256_1mm", 356.0, "DESIGN 3.1: 8x24.12 + 24x5.36 + 8x2.93 + 16x0.69 (oracle counters, projection 0)"),
 }
-KERNEL_SOURCES = ("track_pool.inc", "track_common.inc", "device_model.hpp", "track_fast.hip", "Makefile")
+KERNEL_SOURCES = ("track_pool.inc", "track_common.inc", "device_model.hpp", "track_fast.hip")
 
 
 def kernel_source_hash() -> str:
-    """Identifies the FAST kernel build: SHA-256 over the sources and the build recipe of track_fast.o."""
+    """Identifies the FAST kernel build: SHA-256 over its sources and over the compiler flags of track_fast.o (the
+    CXXFLAGS / HIPFLAGS / FASTMATH lines of the Makefile)."""
     h = hashlib.sha256()
+    csrc = ROOT / "4d-cbct-mc_amd" / "csrc"
     for name in KERNEL_SOURCES:
-        h.update((ROOT / "4d-cbct-mc_amd" / "csrc" / name).read_bytes())
+        h.update((csrc / name).read_bytes())
+    for line in (csrc / "Makefile").read_text().split("\n"):
+        if line.startswith(("CXXFLAGS", "HIPFLAGS", "FASTMATH")):
+            h.update(line.encode())
     return h.hexdigest()[:16]
 
 
