@@ -109,3 +109,70 @@ def test_thorax_compat_bit_exact_and_fast_statistical_parity(thorax512):
     img_cpu, _ = T.track(223, 9, 0, 512, 150, ol.MATH_PORTABLE, n_threads=ORACLE_THREADS)
     assert np.array_equal(img_gpu.reshape(-1), img_cpu) and img_gpu.sum() > 0
     _fast_vs_oracle(ctx, 223, n_gpu=200_000_000, n_cpu_batches=200_000, block=16, label="thorax512")
+
+
+# ------------------------------------------------------------------ configs 3 and 5: the bundled CIRS phantom at full size
+@pytest.fixture(scope="module")
+def cirs_full(engine, tmp_path_factory):
+    import bench
+    wd = tmp_path_factory.mktemp("cirs_full")
+    inp = bench.build_workload(wd, "cirs", int(1e8), 894, engine)
+    with engine.create(inp, device=0) as ctx:
+        yield ctx
+
+
+def test_cirs_full_size_compat_bit_exact_and_fast_statistical_parity(cirs_full):
+    """305 x 300 x 152 voxels of 1 mm (the non-square slice of the bundled phantom, 8^3-voxel bricks), tumour insert placed,
+    the reference's tissue tables with 29-40 shells."""
+    ctx = cirs_full
+    # engine frame = rot90(k=3) of the (305, 300, 152) geometry arrays in the x/y plane
+    assert (ctx.geti("num_voxels_x"), ctx.geti("num_voxels_y"), ctx.geti("num_voxels_z")) == (300, 305, 152)
+    assert ctx.detector_shape == (768, 1848) and ctx.num_projections == 894 and ctx.geti("volume_kind") == 0
+    T = parity.tables_from_context(ctx)
+    for p in (0, 600):
+        img_gpu, _, done = ctx.run_projection(p, 512, mode="compat", seed=3 + p, hpt=150)
+        img_cpu, _ = T.track(p, 3 + p, 0, 512, 150, ol.MATH_PORTABLE, n_threads=ORACLE_THREADS)
+        assert done == 512 * 150 and img_gpu.sum() > 0
+        assert np.array_equal(img_gpu.reshape(-1), img_cpu), p
+    _fast_vs_oracle(ctx, 600, n_gpu=200_000_000, n_cpu_batches=250_000, block=8, label="cirs_full")
+
+
+def _split_voxels(vox):
+    """host table voxel_mat_dens: float2 {material number + 0.0001f, density} per voxel (MC-GPU_v1.3.cu:2135-2136)"""
+    return vox[..., 0].astype(np.int32).astype(np.uint8), vox[..., 1]
+
+
+def test_cirs_full_size_respiratory_state_on_the_device(cirs_full):
+    """One respiratory state of config 5 at full size: the geometry warped and re-indexed on the device
+    (mcgpu_warp_geometry) holds the voxels of the restated warp (tests/warp_ref.py, pinned by the torch fixture), and the
+    COMPAT tallies on it equal the oracle's on the downloaded voxels -- bit for bit; the identity field restores the base."""
+    import warp_ref
+    ctx = cirs_full
+    base_vox = ctx.host_table("voxel_mat_dens", "<f4").copy()
+    base_wood = ctx.host_table("mfp_woodcock").copy()
+    geo = cases.pkg.geometry.MCCIRSPhantomGeometry.from_base_geometry().place_insert()
+    shape = geo.materials.shape
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n, dtype=np.float32) for n in shape], indexing="ij")
+    # sinusoidal SI motion of <= 15 mm (SURVEY 8d, input 4) with a smaller in-plane component
+    field = np.stack([2.0 * np.sin(2.0 * y) * (1 - z * z), 1.5 * x * z, 15.0 * np.cos(1.5 * x) * np.cos(1.2 * y) * (1 - z * z)]).astype(np.float32)
+    ctx.warp_geometry(field, frame="geometry")
+    try:
+        air = cases.materials.material_number("air")
+        wm, wd = warp_ref.warp_nearest(geo.materials, geo.densities, field, air, cases.materials.MATERIALS_125KEV["air"])
+        assert (wm != geo.materials).sum() > 100_000
+        # the voxel file order: rot90(k=3) in the x/y plane, x fastest (create_mcgpu_geometry, cbctmc/mc/geometry.py:589-599)
+        vox = ctx.host_table("voxel_mat_dens", "<f4").reshape(shape[2], shape[0], shape[1], 2)  # [z, y_e, x_e, {material, density}]
+        want_m = np.transpose(np.rot90(wm, k=3, axes=(0, 1)), (2, 1, 0))
+        want_d = np.transpose(np.rot90(wd, k=3, axes=(0, 1)), (2, 1, 0))
+        got_m, got_d = _split_voxels(vox)
+        assert np.array_equal(got_m, want_m) and np.array_equal(got_d, want_d.astype(np.float32))
+        T = parity.tables_from_context(ctx)
+        img_gpu, _, done = ctx.run_projection(300, 512, mode="compat", seed=11, hpt=150)
+        img_cpu, _ = T.track(300, 11, 0, 512, 150, ol.MATH_PORTABLE, n_threads=ORACLE_THREADS)
+        assert done == 512 * 150 and np.array_equal(img_gpu.reshape(-1), img_cpu) and img_gpu.sum() > 0
+        a, _, _ = ctx.run_projection(300, 2_000_000, mode="fast", seed=5)
+        assert a.sum() > 0
+    finally:
+        ctx.warp_geometry(np.zeros_like(field), frame="geometry")
+    assert np.array_equal(ctx.host_table("voxel_mat_dens", "<f4"), base_vox)
+    assert np.array_equal(ctx.host_table("mfp_woodcock"), base_wood)
