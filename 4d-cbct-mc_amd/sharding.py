@@ -62,25 +62,31 @@ def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "sca
     # `world` of them below 2^32 for step 3 (sent as low words)
     wire1 = torch.int32 if top < 2 ** 31 else torch.int64
     wire2 = torch.int32 if top * world < 2 ** 32 else torch.int64  # low words; widened again with a mask on `dst`
-    key = (n, world, str(image.device), wire1, wire2)
+    key = (n, world, str(image.device))
     buf = _BUFFERS.get(key)
-    if buf is None:  # staging buffers are kept: a bench step must not pay allocations and memsets of a few hundred MB
-        _BUFFERS.clear()
-        buf = _BUFFERS[key] = {"send": torch.zeros(world * m, dtype=wire1, device=image.device),
-                               "recv": torch.empty(world * m, dtype=wire1, device=image.device),
-                               "full": torch.empty(world * m, dtype=wire2, device=image.device) if rank == dst else None}
-    send, recv = buf["send"], buf["recv"]
-    send[:n].copy_(flat)  # narrowing copy (the tail beyond n stays zero)
+    if buf is None:  # staging buffers are kept: a bench step must not pay allocations of a few hundred MB
+        while len(_BUFFERS) >= _MAX_BUFFER_SETS:  # a few payload shapes stay resident (full groups and a remainder group)
+            _BUFFERS.pop(next(iter(_BUFFERS)))
+        # sized for 64-bit words and viewed as 32-bit ones when the payload is narrowed: one set serves both wire formats
+        buf = _BUFFERS[key] = {"send": torch.empty(world * m, dtype=torch.int64, device=image.device),
+                               "recv": torch.empty(world * m, dtype=torch.int64, device=image.device),
+                               "full": torch.empty(world * m, dtype=torch.int64, device=image.device) if rank == dst else None}
+    as_wire = lambda b, w: b if w == torch.int64 else b.view(torch.int32)[:world * m]
+    send, recv = as_wire(buf["send"], wire1), as_wire(buf["recv"], wire1)
+    full = as_wire(buf["full"], wire2) if rank == dst else None
+    send[:n].copy_(flat)  # narrowing copy
+    send[n:].zero_()      # padding of the last slice
     dist.all_to_all_single(recv, send)
     part = recv.view(world, m).sum(dim=0, dtype=torch.int64)
     part_w = part if wire2 == torch.int64 else part.to(torch.int32)  # keeps the low 32 bits
-    parts = list(buf["full"].view(world, m).unbind(0)) if rank == dst else None
+    parts = list(full.view(world, m).unbind(0)) if rank == dst else None
     dist.gather(part_w, parts, dst=dst)
     if rank == dst:
-        flat.copy_(buf["full"][:n])  # widening copy (sign-extends)
+        flat.copy_(full[:n])  # widening copy (sign-extends)
         if wire2 == torch.int32:
             flat.bitwise_and_(0xFFFFFFFF)
     return send.numel() * send.element_size() + part_w.numel() * part_w.element_size()
 
 
 _BUFFERS: dict = {}
+_MAX_BUFFER_SETS = 4

@@ -307,6 +307,10 @@ def main():
         step(i, False)
     drain()
     if dist:
+        # the reductions of the timed region (full groups of G projections and the remainder group) run once untimed: RCCL
+        # sets up its channels and sharding.reduce_image its staging buffers on the first call with a payload shape
+        for size in sorted({G if args.steps >= G else 0, args.steps % G} - {0}):
+            cases.pkg.sharding.reduce_image(images[:size], dst=0, narrow=narrow, algorithm=reduce_algo)
         dist.barrier()
     torch.cuda.synchronize()
     reduce_bytes[0] = 0
