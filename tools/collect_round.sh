@@ -10,6 +10,11 @@ cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats
 head -1 $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/bench_kernel_trace_track.csv; grep track_ $(find $OUT/prof -name "*kernel_trace.csv" | head -1) >> $OUT/bench_kernel_trace_track.csv
 bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json
 bash tools/pmc_collect.sh $OUT/pmc_thorax --workload thorax --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > /dev/null 2>&1; cp $OUT/pmc_thorax/summary.json $OUT/pmc_summary_thorax.json
+bash tools/pmc_collect.sh $OUT/pmc_cirs --workload cirs --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > /dev/null 2>&1; cp $OUT/pmc_cirs/summary.json $OUT/pmc_summary_cirs.json
+# the drop-in default: ASCII projection files formatted on the device (kernel stats of a 24-projection scan)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ascii -- python3 tools/scan_ascii.py 24 > $OUT/scan_ascii.log 2> $OUT/scan_ascii.err
+cp $(find $OUT/prof_ascii -name "*kernel_stats.csv" | head -1) $OUT/scan_ascii_kernel_stats.csv
+python3 tools/scan_ascii.py 200 > $OUT/scan_ascii_200.log 2>&1
 BENCH_FORCE_DIST=1 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_line_forced_collective.json 2> $OUT/forced.err
-rm -rf $OUT/prof $OUT/pmc/pass* $OUT/pmc_thorax/pass*
+rm -rf $OUT/prof $OUT/prof_ascii $OUT/pmc/pass* $OUT/pmc_thorax/pass* $OUT/pmc_cirs/pass*
 ls -la $OUT
