@@ -614,7 +614,6 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   // batching thresholds (lanes of a wave64); tunable for experiments
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? env_int("MCGPU_EXTERIOR_MODE", 3) : 0;  // bit 0: hop during flight, bit 1: hop at the source
-  if (getenv("MCGPU_DEBUG_NO_TALLY")) A.has_exterior |= 4 * atoi(getenv("MCGPU_DEBUG_NO_TALLY"));  // 1: none, 2: plain store, 4: 32-bit atomic  // experiment: FAST kernel without its detector atomics (wrong images)
   // batching thresholds of the COMPAT kernel (one history per lane)
   A.thresh_compton = env_int("MCGPU_COMPAT_THRESH_COMPTON", 20);
   A.thresh_rayleigh = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", 6);
@@ -1061,10 +1060,8 @@ int mcgpu_write_formatted_projection(mcgpu_ctx* ctx, int p, int slot, unsigned l
   const unsigned int flags = (unsigned int)rows[5 * nz + 1];
   require(flags == 0u, -3, "!!ERROR!! projection values outside the range of the device formatter (>= 1e11 eV/cm^2 per history)");
   const size_t bytes = (size_t)rows[2 * nz];  // row_off[nz]
-  const auto t_a = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(S.text_host, S.text_dev, bytes, hipMemcpyDeviceToHost, D.copy_stream));
   HIP_TRY(hipStreamSynchronize(D.copy_stream));
-  const auto t_b = std::chrono::steady_clock::now();
   // footer inputs: the rows in order (the first of equal maxima wins, MC-GPU_v1.3.cu:2893-2897)
   const long long* arg = (const long long*)(rows + 2 * nz + 1);
   const double* sum = (const double*)(rows + 3 * nz + 1);
@@ -1077,9 +1074,6 @@ int mcgpu_write_formatted_projection(mcgpu_ctx* ctx, int p, int slot, unsigned l
   }
   const std::string name = file_name ? std::string(file_name) : projection_file_name(ctx->host, p);
   write_projection_preformatted(ctx->host, p, S.text_host, bytes, integral, maximum, max_pixel, total_histories, seconds, name);
-  if (getenv("MCGPU_ASCII_TIMING"))
-    fprintf(stderr, "ascii: %zu bytes, download %.2f ms, file %.2f ms\n", bytes, std::chrono::duration<double, std::milli>(t_b - t_a).count(),
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
   return 0;
   ABI_END
 }
