@@ -54,16 +54,16 @@ struct DeviceModel {
   int vol_kind = kVolU8, palette_size = 0;
   float* palette = nullptr;
   unsigned char* bricks = nullptr;
-  // on-device formatter of the ASCII projection files (mcgpu_format_projection): two slots, so that the host writes one
-  // projection's text while the next is formatted
+  // on-device formatter of the ASCII projection files (mcgpu_format_projection): a few slots, so that the host writes
+  // the text of earlier projections while the next is formatted
   struct AsciiSlot {
     char* text_dev = nullptr;
     char* text_host = nullptr;            // pinned
     unsigned long long* rows_dev = nullptr;   // row_len[nz] row_off[nz+1] row_arg[nz] | row_sum[nz] row_max[nz] | flags
     unsigned long long* rows_host = nullptr;  // pinned copy of the same block
-  } ascii[2];
+    hipStream_t copy_stream = nullptr;        // the slot's download (copy engine)
+  } ascii[MCGPU_ASCII_SLOTS];
   unsigned long long ascii_capacity = 0;
-  hipStream_t copy_stream = nullptr;
   // on-device geometry changes (mcgpu_warp_geometry): the base geometry's palette index volume, scratch, the palette on the
   // host and the code assignment of the base geometry
   unsigned char* vol_base = nullptr;
@@ -131,10 +131,9 @@ struct DeviceModel {
     for (AsciiSlot& a : ascii) {
       if (a.text_host) (void)hipHostFree(a.text_host);
       if (a.rows_host) (void)hipHostFree(a.rows_host);
+      if (a.copy_stream) (void)hipStreamDestroy(a.copy_stream);
       a = AsciiSlot();
     }
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    copy_stream = nullptr;
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
     ev_start = ev_stop = nullptr;
@@ -1013,7 +1012,7 @@ static size_t ascii_row_words(int nz) { return (size_t)5 * nz + 2; }
 
 int mcgpu_format_projection(mcgpu_ctx* ctx, const void* image_dev, unsigned long long total_histories, int slot, void* hip_stream) {
   ABI_BEGIN
-  require(ctx && ctx->has_device && image_dev && (slot == 0 || slot == 1) && total_histories > 0, -1, "!!ERROR!! mcgpu_format_projection: bad argument");
+  require(ctx && ctx->has_device && image_dev && slot >= 0 && slot < MCGPU_ASCII_SLOTS && total_histories > 0, -1, "!!ERROR!! mcgpu_format_projection: bad argument");
   DeviceModel& D = ctx->dev;
   HIP_TRY(hipSetDevice(D.device_id));
   const DetectorPose& d0 = ctx->host.detector[0];
@@ -1031,7 +1030,7 @@ int mcgpu_format_projection(mcgpu_ctx* ctx, const void* image_dev, unsigned long
     S.rows_dev = D.put(std::vector<unsigned long long>(words, 0ULL));
     HIP_TRY(hipHostMalloc((void**)&S.text_host, D.ascii_capacity, hipHostMallocNonCoherent));
     HIP_TRY(hipHostMalloc((void**)&S.rows_host, words * 8, hipHostMallocDefault));
-    if (!D.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
   }
   AsciiArgs a;
   a.image = (const unsigned long long*)image_dev;
@@ -1049,7 +1048,7 @@ int mcgpu_format_projection(mcgpu_ctx* ctx, const void* image_dev, unsigned long
 
 int mcgpu_write_formatted_projection(mcgpu_ctx* ctx, int p, int slot, unsigned long long total_histories, double seconds, const char* file_name) {
   ABI_BEGIN
-  require(ctx && ctx->has_device && (slot == 0 || slot == 1) && p >= 0 && p < ctx->host.cfg.num_projections && total_histories > 0, -1,
+  require(ctx && ctx->has_device && slot >= 0 && slot < MCGPU_ASCII_SLOTS && p >= 0 && p < ctx->host.cfg.num_projections && total_histories > 0, -1,
           "!!ERROR!! mcgpu_write_formatted_projection: bad argument");
   DeviceModel& D = ctx->dev;
   DeviceModel::AsciiSlot& S = D.ascii[slot];
@@ -1060,8 +1059,8 @@ int mcgpu_write_formatted_projection(mcgpu_ctx* ctx, int p, int slot, unsigned l
   const unsigned int flags = (unsigned int)rows[5 * nz + 1];
   require(flags == 0u, -3, "!!ERROR!! projection values outside the range of the device formatter (>= 1e11 eV/cm^2 per history)");
   const size_t bytes = (size_t)rows[2 * nz];  // row_off[nz]
-  HIP_TRY(hipMemcpyAsync(S.text_host, S.text_dev, bytes, hipMemcpyDeviceToHost, D.copy_stream));
-  HIP_TRY(hipStreamSynchronize(D.copy_stream));
+  HIP_TRY(hipMemcpyAsync(S.text_host, S.text_dev, bytes, hipMemcpyDeviceToHost, S.copy_stream));
+  HIP_TRY(hipStreamSynchronize(S.copy_stream));
   // footer inputs: the rows in order (the first of equal maxima wins, MC-GPU_v1.3.cu:2893-2897)
   const long long* arg = (const long long*)(rows + 2 * nz + 1);
   const double* sum = (const double*)(rows + 3 * nz + 1);

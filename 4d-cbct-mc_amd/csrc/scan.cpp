@@ -37,6 +37,8 @@ hipError_t launch_accumulate(unsigned long long* dst, const unsigned long long* 
 
 namespace {
 
+constexpr int kAsciiSlots = MCGPU_ASCII_SLOTS;
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct ScanError {
@@ -85,14 +87,15 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     bool abort = false;
     std::string error;
     double writer_s = 0.0;
-    // ASCII files of the device formatter: one worker per slot, so that two files are written side by side (writes to
-    // ONE file do not scale with threads -- they serialise on its inode lock -- writes to two files do)
-    bool ascii_busy[2] = {false, false};
-    int ascii_p[2] = {0, 0};
-    double ascii_seconds[2] = {0.0, 0.0};
+    // ASCII files of the device formatter: one worker per slot, so that several files are written side by side (writes
+    // to ONE file do not scale with threads -- they serialise on its inode lock -- writes to different files do)
+    bool ascii_busy[kAsciiSlots] = {};
+    int ascii_p[kAsciiSlots] = {};
+    double ascii_seconds[kAsciiSlots] = {};
     bool ascii_quit = false;
   } sh;
-  std::thread ascii_worker[2];
+  std::thread ascii_worker[kAsciiSlots];
+  int n_ascii = kAsciiSlots;  // formatter slots in use = files written side by side
   mcgpu_ctx* ctx = ctxs[0];
   int rc = 0;
   try {
@@ -155,6 +158,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     // ---- device resources
     const unsigned int pinned_flags = getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent;
     const bool ascii_on_host = getenv("MCGPU_ASCII_HOST") != nullptr;  // A/B: the threaded host formatter of report.cpp
+    if (const char* w = getenv("MCGPU_ASCII_WRITERS")) n_ascii = std::min(std::max(atoi(w), 1), kAsciiSlots);
     const bool single = (n_ctx == 1);
     for (int g = 0; g < n_ctx; ++g) {
       HIP_OK(hipSetDevice(D[g].dev));
@@ -243,7 +247,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     std::vector<float> kms(count, 0.f);  // kernel time per projection (written before the projection is queued)
     const bool ascii_async = opt->write_ascii && !ascii_on_host;
     if (ascii_async)
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < n_ascii; ++b)
         ascii_worker[b] = std::thread([&, b]() {
           for (;;) {
             int p;
@@ -303,10 +307,11 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         }
         if (wrc == 0 && opt->write_ascii && ascii_on_host) wrc = mcgpu_write_projection(ctx, p, image_host[b], total, (double)kms[i] * 1e-3, nullptr);
         std::lock_guard<std::mutex> lk(sh.mu);
-        if (wrc == 0 && ascii_async) {  // slot b is free: the projection loop waited for that before it formatted into it
-          sh.ascii_p[b] = p;
-          sh.ascii_seconds[b] = (double)kms[i] * 1e-3;
-          sh.ascii_busy[b] = true;
+        if (wrc == 0 && ascii_async) {  // the slot is free: the projection loop waited for that before it formatted into it
+          const int a = i % n_ascii;
+          sh.ascii_p[a] = p;
+          sh.ascii_seconds[a] = (double)kms[i] * 1e-3;
+          sh.ascii_busy[a] = true;
         }
         sh.writer_s += now_s() - tw0;
         if (wrc != 0) { sh.error = mcgpu_last_error(); sh.abort = true; }
@@ -328,7 +333,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       const int b = j & 1, t = single ? 0 : b;
       {  // pinned buffer b is free once projection j-2 has been written
         std::unique_lock<std::mutex> lk(sh.mu);
-        sh.cv.wait(lk, [&] { return (sh.written >= j - 1 && !sh.ascii_busy[b]) || sh.abort; });
+        sh.cv.wait(lk, [&] { return (sh.written >= j - 1 && !sh.ascii_busy[j % n_ascii]) || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
       HIP_OK(hipSetDevice(D[0].dev));
@@ -341,7 +346,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       // cleared; the writer thread downloads and writes them while the next projection is tracked
       if (opt->write_ascii) {
         if (ascii_on_host) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, s0));
-        else ABI_OK(mcgpu_format_projection(ctx, D[0].image[t], total, b, s0));
+        else ABI_OK(mcgpu_format_projection(ctx, D[0].image[t], total, j % n_ascii, s0));
       }
       ABI_OK(mcgpu_finalize_projection(ctx, D[0].image[t], total, cx, planes_dev[b], 1, s0));
       HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, s0));
@@ -398,7 +403,11 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     writer.join();
     {
       std::unique_lock<std::mutex> lk(sh.mu);
-      sh.cv.wait(lk, [&] { return (!sh.ascii_busy[0] && !sh.ascii_busy[1]) || sh.abort; });
+      sh.cv.wait(lk, [&] {
+        bool busy = false;
+        for (bool b : sh.ascii_busy) busy = busy || b;
+        return !busy || sh.abort;
+      });
       sh.ascii_quit = true;
       sh.cv.notify_all();
     }

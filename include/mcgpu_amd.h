@@ -122,9 +122,11 @@ int mcgpu_write_projection(mcgpu_ctx *ctx, int p, const uint64_t *image_host, un
 /* report_image with the 1.4 M data lines formatted ON THE DEVICE (MC-GPU_v1.3.cu:2860-2904: four "%.8lf" numbers per pixel,
  * a blank line per detector row; exact decimal conversion in integer arithmetic, byte-identical to mcgpu_write_projection).
  * mcgpu_format_projection is asynchronous on `hip_stream`: it reads the device tally `image_dev` (before it is cleared) and
- * fills one of two internal slots; once the stream has passed that point (event / synchronize), the host side
+ * fills one of MCGPU_ASCII_SLOTS internal slots; once the stream has passed that point (event / synchronize), the host side
  * mcgpu_write_formatted_projection downloads the text with a copy engine and writes header + text + footer.  The scan driver
- * alternates the slots, so the file of projection i is written while i + 1 is tracked and formatted. */
+ * cycles through the slots with one writer thread each, so the files of projections i - 2 .. i are written side by side
+ * while i + 1 is tracked and formatted.  Different slots may be used from different threads at the same time. */
+#define MCGPU_ASCII_SLOTS 3
 int mcgpu_format_projection(mcgpu_ctx *ctx, const void *image_dev, unsigned long long total_histories, int slot, void *hip_stream);
 int mcgpu_write_formatted_projection(mcgpu_ctx *ctx, int p, int slot, unsigned long long total_histories, double seconds,
                                      const char *file_name);

@@ -93,6 +93,26 @@ def test_fast_statistical_parity_at_full_size(catphan512, p):
     _fast_vs_oracle(catphan512, p, n_gpu=200_000_000, n_cpu_batches=340_000, block=8, label="catphan512")
 
 
+def test_device_formatted_projection_file_at_full_detector_size(catphan512, tmp_path):
+    """63 MB of text per projection: the rows of the 1848-pixel detector span eight 256-pixel tiles of the device formatter,
+    the row offsets run past 2^25; byte-identical to the host writer on a real projection and on random tallies."""
+    import torch
+    ctx = catphan512
+    nz, nx = ctx.detector_shape
+    rng = np.random.default_rng(3)
+    real, _, done = ctx.run_projection(100, 20_000_000, mode="fast", seed=8)
+    rnd = (rng.random((4, nz, nx)) * 2.0 ** rng.integers(0, 50, size=(4, nz, nx))).astype(np.uint64)
+    rnd[rng.random(rnd.shape) < 0.2] = 0
+    for k, (img, n_hist) in enumerate(((real, done), (rnd, 1_000_003))):
+        dev = torch.from_numpy(np.ascontiguousarray(img).view(np.int64)).cuda()
+        want, got = tmp_path / f"host_{k}", tmp_path / f"device_{k}"
+        ctx.write_projection(100, img, n_hist, 1.5, file_name=str(want))
+        ctx.write_projection_device(100, dev.data_ptr(), n_hist, 1.5, file_name=str(got), slot=2 - k)
+        a, b = want.read_bytes(), got.read_bytes()
+        assert len(a) == len(b) > 60_000_000 * (k == 0) and a == b, (k, len(a), len(b))
+        want.unlink(); got.unlink()
+
+
 def test_thorax_shape_and_lds_budget(thorax512):
     ctx = thorax512
     assert (ctx.geti("num_voxels_x"), ctx.geti("num_voxels_y"), ctx.geti("num_voxels_z")) == (512, 512, 256)

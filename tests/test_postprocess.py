@@ -227,7 +227,7 @@ def test_device_formatted_projection_file_is_byte_identical(engine, case_dir, tm
         nz, nx = ctx.detector_shape
         for k, n_hist in enumerate((1_000_000, 3, 2 ** 20, 123_456_789)):
             norm = 0.01 * (10.0 / ctx.getf("pixel_size_x_mm")) * (10.0 / ctx.getf("pixel_size_z_mm")) / n_hist
-            top = int(np.log2(5.0e9 / norm))  # values up to 5e9 eV/cm^2 per history: 10 integer digits (physical ones have <= 6)
+            top = min(int(np.log2(9.0e10 / norm)), 62)  # values up to 9e10 eV/cm^2 per history: 11 integer digits (physical ones have <= 6)
             img = np.zeros((4, nz, nx), dtype=np.uint64)
             mag = rng.integers(0, top, size=img.shape)
             img[:] = (rng.random(img.shape) * (2.0 ** mag)).astype(np.uint64)
@@ -241,6 +241,14 @@ def test_device_formatted_projection_file_is_byte_identical(engine, case_dir, tm
             want = tmp_path / f"host_{k}"
             got = tmp_path / f"device_{k}"
             ctx.write_projection(1, img, n_hist, 2.5, file_name=str(want))
-            ctx.write_projection_device(1, dev.data_ptr(), n_hist, 2.5, file_name=str(got), slot=k & 1)
+            ctx.write_projection_device(1, dev.data_ptr(), n_hist, 2.5, file_name=str(got), slot=k % 3)
             a, b = want.read_bytes(), got.read_bytes()
             assert len(a) == len(b) and a == b, (k, len(a), len(b))
+        # 12 integer digits: outside the formatter's buffers -- refused, nothing is written
+        img[:] = 0
+        n_hist = 3
+        img[3, 5, 7] = int(2.0e11 / (0.01 * (10.0 / ctx.getf("pixel_size_x_mm")) * (10.0 / ctx.getf("pixel_size_z_mm")) / n_hist))
+        dev = torch.from_numpy(img.view(np.int64)).cuda()
+        with pytest.raises(engine.EngineError) as e:
+            ctx.write_projection_device(1, dev.data_ptr(), n_hist, 2.5, file_name=str(tmp_path / "refused"), slot=0)
+        assert e.value.code == -3 and not (tmp_path / "refused").exists()
