@@ -93,7 +93,6 @@ struct TrackArgs {
   int brick_shift, brick_nx, brick_nxy, brick_bytes;
   const unsigned char* sub;  // FAST: second-level codes, 4 bits per 4^3-voxel sub-brick, dense (null: none)
   int sub_nx, sub_nxy;
-  float brick_scale[3];  // inv_vs / 2^brick_shift: position -> brick coordinate
   int nx, ny, nz, nxy;
   float inv_vs[3];
   float bbox[3];

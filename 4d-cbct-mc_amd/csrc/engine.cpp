@@ -594,7 +594,6 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   for (int k = 0; k < 3; ++k) {
     A.inv_vs[k] = H.voxels.inv_voxel_size[k];
     A.bbox[k] = H.voxels.size_bbox[k];
-    A.brick_scale[k] = H.voxels.inv_voxel_size[k] / (float)(1 << D.brick_shift);  // exact: a power-of-two scaling
     // upper clamp of the FAST kernel: bbox - EPS_SOURCE (MC-GPU_v1.3.h:87), lowered until it indexes the last voxel
     float hi = A.bbox[k] - 0.000015f;
     while ((int)(hi * A.inv_vs[k]) > H.voxels.n[k] - 1) hi = std::nextafter(hi, 0.0f);
@@ -895,7 +894,9 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
         TrackCold& ch = D.cold_host;
         const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", D.sched[0]), env_int("MCGPU_THRESH_RAYLEIGH", D.sched[1]), env_int("MCGPU_THRESH_NEW", D.sched[2]),
                               std::max(1, env_int("MCGPU_FLYABLE_LOW", D.sched[3])), std::max(1, env_int("MCGPU_SWAP_BATCH", D.sched[4]))};
-        const int trade = getenv("MCGPU_SLOT_TRADE") ? atoi(getenv("MCGPU_SLOT_TRADE")) : 3;  // bit 0: before flight, bit 1: before the Compton and tally/source services
+        // bit 0: slots traded before flight, bit 1: before the Compton and tally/source services; bits 8-11: hold_q (sixteenths
+        // of the flying lanes that end a flight segment at the latest)
+        const int trade = env_int("MCGPU_SLOT_TRADE", 3) | ((env_int("MCGPU_HOLD_Q", 6) & 15) << 8);
         if (ch.trade_slots != trade || ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
             ch.swap_batch != want5[4]) {
           ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];
