@@ -1,16 +1,17 @@
 #!/bin/bash
-# End-of-round measurement set (GPU box, repo root): bench lines, rocprofv3 kernel stats and PMC passes -> gpurun_out/<tag>/
+# End-of-round measurement set (GPU box, repo root): PMC passes first (their summaries are what the bench lines quote as
+# roofline.traffic, stamped with the kernel's source hash), then bench lines, rocprofv3 kernel stats -> gpurun_out/<tag>/
 # Usage: bash tools/collect_round.sh r02
 TAG=${1:-r02}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat"
+bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json; cp $OUT/pmc/summary.json profiles/pmc_summary_latest.json
+for wl in thorax cirs; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 for wl in cirs thorax; do python bench.py --workload $wl > $OUT/bench_line_$wl.json 2> $OUT/bench_line_$wl.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 head -1 $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/bench_kernel_trace_track.csv; grep track_ $(find $OUT/prof -name "*kernel_trace.csv" | head -1) >> $OUT/bench_kernel_trace_track.csv
-bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json
-bash tools/pmc_collect.sh $OUT/pmc_thorax --workload thorax --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > /dev/null 2>&1; cp $OUT/pmc_thorax/summary.json $OUT/pmc_summary_thorax.json
-bash tools/pmc_collect.sh $OUT/pmc_cirs --workload cirs --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > /dev/null 2>&1; cp $OUT/pmc_cirs/summary.json $OUT/pmc_summary_cirs.json
 # the drop-in default: ASCII projection files formatted on the device (kernel stats of a 24-projection scan)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ascii -- python3 tools/scan_ascii.py 24 > $OUT/scan_ascii.log 2> $OUT/scan_ascii.err
 cp $(find $OUT/prof_ascii -name "*kernel_stats.csv" | head -1) $OUT/scan_ascii_kernel_stats.csv
