@@ -246,6 +246,27 @@ def cases_root():
     return Path(__file__).resolve().parents[1]
 
 
+def test_fast_kernel_history_ids_beyond_32_bits(gpu_engine, case_dir):
+    """BASELINE config 3 asks for 1.19e10 histories per projection: history ids (the Philox counter), id ranges of a rank and
+    the launch size itself pass 2^32.  A range that straddles 2^32 equals the sum of its two halves; a 5e9-history launch
+    simulates exactly that many and agrees with 50 x a 1e8-history launch within the statistics of the latter."""
+    with gpu_engine.create(case_dir("water"), device=0) as ctx:
+        lo = 2 ** 32 - 70_000
+        whole, _, done = ctx.run_projection(0, 150_000, mode="fast", seed=3, first=lo)
+        a, _, da = ctx.run_projection(0, 70_000, mode="fast", seed=3, first=lo)
+        b, _, db = ctx.run_projection(0, 80_000, mode="fast", seed=3, first=2 ** 32)
+        assert done == 150_000 and da + db == done and np.array_equal(a + b, whole) and b.sum() > 0
+        low, _, _ = ctx.run_projection(0, 80_000, mode="fast", seed=3, first=0)
+        assert not np.array_equal(low, b)  # ids 2^32 + k are not ids k
+        small, _, ds = ctx.run_projection(0, 100_000_000, mode="fast", seed=9)
+        big, _, dbig = ctx.run_projection(0, 5_000_000_000, mode="fast", seed=9, first=2 ** 33)
+        assert ds == 100_000_000 and dbig == 5_000_000_000
+        for k in range(4):
+            es, eb = float(small[k].sum()), float(big[k].sum())
+            hits = max(es / 5.0e6, 1.0)  # ~ number of detected photons of the small run (tally unit 0.01 eV, ~50 keV each)
+            assert abs(eb / 50.0 - es) < 6.0 * es / np.sqrt(hits) + 1.0, (k, es, eb)
+
+
 def test_fast_kernel_small_and_ragged_history_counts(gpu_engine, case_dir):
     """History ids are dealt from 64 counters that each own count/64 ids (one more for the first count % 64): launches of 0, 1,
     63, 64, 65, ... histories simulate exactly that many, every id once -- the tallies of id ranges add up to the whole."""
