@@ -419,11 +419,21 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     }
     float repl[3] = {0.f, 0.f, 0.f};
     if (opt->write_stacks && !shared && count > 0) {
+      // zero replacement and close of the three stacks side by side (page-cache work on three different files)
+      int rc3[3] = {0, 0, 0};
+      std::string err3[3];
+      std::thread fin[3];
       for (int k = 0; k < 3; ++k) {
         mcgpu_stack* s = stacks[k];
         stacks[k] = nullptr;
-        ABI_OK(mcgpu_stack_finish(s, 1, &repl[k]));
+        fin[k] = std::thread([&, k, s] {
+          rc3[k] = mcgpu_stack_finish(s, 1, &repl[k]);
+          if (rc3[k] != 0) err3[k] = mcgpu_last_error();  // the last error is per thread
+        });
       }
+      for (auto& t : fin) t.join();
+      for (int k = 0; k < 3; ++k)
+        if (rc3[k] != 0) throw ScanError{rc3[k], err3[k]};
       if (opt->air_stack)
         ABI_OK(mcgpu_normalize_stack((folder + "/projections_total.mha").c_str(), opt->air_stack, opt->air_sigma_y, opt->air_sigma_x,
                                      (folder + "/projections_total_normalized.mha").c_str(), sx, sy));
