@@ -231,6 +231,7 @@ size_t write_projection_ascii(const HostModel& m, int p, const uint64_t* image, 
       return v;
     }
     void give(std::vector<char>* v) { std::lock_guard<std::mutex> lk(mu); free_list.push_back(v); }
+    ~BandPool() { for (auto* v : free_list) delete v; }
   };
   static BandPool pool;
   std::vector<Band> chunks(T);
