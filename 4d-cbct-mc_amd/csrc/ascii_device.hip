@@ -35,7 +35,7 @@ constexpr int kLineMax = 4 * (kIntegerDigits + 9) + 4;      // 4 numbers "i.ffff
 struct Fixed8 {
   unsigned long long ip;  // integer part
   unsigned int frac;      // 8 fractional digits
-  bool ok;                // false: outside the supported range (the host formats that projection)
+  bool ok;                // false: outside the supported range (flag bit 0: mcgpu_write_formatted_projection fails with -3)
 };
 
 // round_half_even(v * 10^8) split at the decimal point; v >= 0 finite
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void ascii_write_kernel(AsciiArgs a) {
   __shared__ unsigned long long s_part[kWaves];
   __shared__ unsigned int s_wave_len[kWaves];
   __shared__ __align__(16) unsigned char s_text[kThreads * kLineMax + 32];
-  if (*a.flags & 1u) return;  // a value outside the formatter's range: the host formats this projection
+  if (*a.flags & 1u) return;  // a value outside the formatter's range: no text; mcgpu_write_formatted_projection reports -3
   const int z = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // where this row starts: the lengths of the rows before it
   unsigned long long g = 0;

@@ -62,6 +62,7 @@ struct DeviceModel {
     unsigned long long* rows_dev = nullptr;   // row_len[nz] row_off[nz+1] row_arg[nz] | row_sum[nz] row_max[nz] | flags
     unsigned long long* rows_host = nullptr;  // pinned copy of the same block
     hipStream_t copy_stream = nullptr;        // the slot's download (copy engine)
+    hipEvent_t ready = nullptr;               // recorded behind the formatter and the download of the row block
   } ascii[MCGPU_ASCII_SLOTS];
   unsigned long long ascii_capacity = 0;
   // on-device geometry changes (mcgpu_warp_geometry): the base geometry's palette index volume, scratch, the palette on the
@@ -100,6 +101,17 @@ struct DeviceModel {
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
   int sched[5] = {32, 8, 36, 12, 40};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
+  // Tuning knobs of the environment.  Read when the device model is built and again only by
+  // mcgpu_reload_env_knobs: the launch path itself never looks at the environment and never synchronises.
+  struct Knobs {
+    int exterior_mode = 3;                           // MCGPU_EXTERIOR_MODE: bit 0 hop during flight, bit 1 hop at the source
+    int compat_thresh[3] = {20, 6, 24};              // MCGPU_COMPAT_THRESH_{COMPTON,RAYLEIGH,NEW}
+    int blocks_per_cu = 0;                           // MCGPU_BLOCKS_PER_CU (0: ask the occupancy API)
+    int grid_spare_percent = 0;                      // MCGPU_GRID_SPARE_PERCENT
+    int sched_override[5] = {-1, -1, -1, -1, -1};    // MCGPU_THRESH_{COMPTON,RAYLEIGH,NEW}, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH (-1: sched[])
+    int slot_trade = 3, hold_q = 6;                  // MCGPU_SLOT_TRADE, MCGPU_HOLD_Q
+    bool no_exterior = false;                        // MCGPU_NO_EXTERIOR (also read by the geometry builders)
+  } knobs;
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;
   unsigned char *itl = nullptr, *itu = nullptr;
@@ -132,6 +144,7 @@ struct DeviceModel {
       if (a.text_host) (void)hipHostFree(a.text_host);
       if (a.rows_host) (void)hipHostFree(a.rows_host);
       if (a.copy_stream) (void)hipStreamDestroy(a.copy_stream);
+      if (a.ready) (void)hipEventDestroy(a.ready);
       a = AsciiSlot();
     }
     if (ev_start) (void)hipEventDestroy(ev_start);
@@ -154,6 +167,46 @@ struct mcgpu_ctx {
 namespace mcgpu {
 namespace {
 
+void read_env_knobs(DeviceModel& D) {
+  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  DeviceModel::Knobs k;
+  k.exterior_mode = env_int("MCGPU_EXTERIOR_MODE", 3);
+  k.compat_thresh[0] = env_int("MCGPU_COMPAT_THRESH_COMPTON", 20);
+  k.compat_thresh[1] = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", 6);
+  k.compat_thresh[2] = env_int("MCGPU_COMPAT_THRESH_NEW", 24);
+  k.blocks_per_cu = std::max(0, env_int("MCGPU_BLOCKS_PER_CU", 0));
+  k.grid_spare_percent = std::max(0, env_int("MCGPU_GRID_SPARE_PERCENT", 0));
+  static const char* const kSched[5] = {"MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH"};
+  for (int i = 0; i < 5; ++i) k.sched_override[i] = env_int(kSched[i], -1);
+  k.slot_trade = env_int("MCGPU_SLOT_TRADE", 3);
+  k.hold_q = env_int("MCGPU_HOLD_Q", 6) & 15;
+  k.no_exterior = getenv("MCGPU_NO_EXTERIOR") != nullptr;
+  D.knobs = k;
+}
+
+// The FAST scheduler's parameters live in TrackCold (device memory read through the scalar cache): effective value =
+// environment override, else the schedule set by mcgpu_set_fast_schedule.  Uploads only when something changed, after the
+// device has drained (callers are set-up paths, never a launch).
+void apply_schedule(DeviceModel& D) {
+  if (!D.cold) return;
+  TrackCold& ch = D.cold_host;
+  int want[5];
+  for (int i = 0; i < 5; ++i) want[i] = D.knobs.sched_override[i] >= 0 ? D.knobs.sched_override[i] : D.sched[i];
+  want[3] = std::max(1, want[3]);
+  want[4] = std::max(1, want[4]);
+  // bit 0: slots traded before flight, bit 1: before the Compton and tally/source services; bits 8-11: hold_q (sixteenths
+  // of the flying lanes that end a flight segment at the latest)
+  const int trade = D.knobs.slot_trade | (D.knobs.hold_q << 8);
+  if (ch.trade_slots == trade && ch.thresh_compton == want[0] && ch.thresh_rayleigh == want[1] && ch.thresh_new == want[2] && ch.flyable_low == want[3] &&
+      ch.swap_batch == want[4])
+    return;
+  ch.thresh_compton = want[0]; ch.thresh_rayleigh = want[1]; ch.thresh_new = want[2]; ch.flyable_low = want[3]; ch.swap_batch = want[4];
+  ch.trade_slots = trade;
+  HIP_TRY(hipSetDevice(D.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(D.cold, &ch, sizeof ch, hipMemcpyHostToDevice));
+}
+
 // Build the palette-compressed volume and the compact-material tables and upload everything.
 void upload_model(mcgpu_ctx& C, int device_id) {
   const HostModel& H = C.host;
@@ -163,6 +216,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   D.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  read_env_knobs(D);
 
   // compact material numbering
   D.nmat = 0;
@@ -317,8 +371,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
             const int c3[3] = {bx, by, bz};
             for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c3[a]); hi[a] = std::max(hi[a], c3[a]); }
           }
-      const bool disable = getenv("MCGPU_NO_EXTERIOR") != nullptr;
-      if (homogeneous[bg] > 0 && hi[0] >= 0 && !disable) {
+      if (homogeneous[bg] > 0 && hi[0] >= 0 && !D.knobs.no_exterior) {
         long outside = 0;
         for (int b = 0; b < D.brick_count; ++b) {
           const int bx = b % D.brick_n[0], by = (b / D.brick_n[0]) % D.brick_n[1], bz = b / (D.brick_n[0] * D.brick_n[1]);
@@ -567,14 +620,16 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
     for (int m = 0; m < kMaxMaterials; ++m) cold.shell_first[m] = D.shell_first[m];
     for (int k = 0; k < 3; ++k) { cold.objbox_lo[k] = D.objbox_lo[k]; cold.objbox_hi[k] = D.objbox_hi[k]; }
-    cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = cold.trade_slots = -1;  // set at launch
+    cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = cold.trade_slots = -1;  // apply_schedule
     D.cold_host = cold;
     D.cold = D.put(std::vector<TrackCold>(1, cold));
     D.src_all = D.put(H.source);
     D.det_all = D.put(H.detector);
   }
+  D.work_counter = D.put(std::vector<unsigned long long>((size_t)kNumCounters * kCounterStride, 0ULL));
   HIP_TRY(hipEventCreate(&D.ev_start));
   HIP_TRY(hipEventCreate(&D.ev_stop));
+  apply_schedule(D);
   HIP_TRY(hipDeviceSynchronize());
 }
 
@@ -609,13 +664,11 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.stream_key = (unsigned)p;
   A.dose_flags = D.dose_flags;
 
-  // batching thresholds (lanes of a wave64); tunable for experiments
-  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? env_int("MCGPU_EXTERIOR_MODE", 3) : 0;  // bit 0: hop during flight, bit 1: hop at the source
-  // batching thresholds of the COMPAT kernel (one history per lane)
-  A.thresh_compton = env_int("MCGPU_COMPAT_THRESH_COMPTON", 20);
-  A.thresh_rayleigh = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", 6);
-  A.thresh_new = env_int("MCGPU_COMPAT_THRESH_NEW", 24);
+  A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? D.knobs.exterior_mode : 0;  // bit 0: hop during flight, bit 1: hop at the source
+  // batching thresholds of the COMPAT kernel (lanes of a wave64, one history per lane)
+  A.thresh_compton = D.knobs.compat_thresh[0];
+  A.thresh_rayleigh = D.knobs.compat_thresh[1];
+  A.thresh_new = D.knobs.compat_thresh[2];
   return A;
 }
 
@@ -877,35 +930,15 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       require(blocks <= 0x7fffffffULL, -2, "!!ERROR!! mcgpu_launch_projection: too many batches");
       HIP_TRY(launch_track_compat(A, (int)blocks, stream));
     } else {
-      // persistent grid: exactly the resident workgroups (an over-subscribed grid would run a second, thin round)
+      // persistent grid: exactly the resident workgroups (an over-subscribed grid would run a second, thin round).  No
+      // getenv and no synchronisation here: the scheduler's parameters were uploaded by apply_schedule.
       if (D.resident_fast <= 0) {
-        const char* v = getenv("MCGPU_BLOCKS_PER_CU");
-        D.resident_fast = v ? atoi(v) : occupancy_track_fast(A);
+        D.resident_fast = D.knobs.blocks_per_cu > 0 ? D.knobs.blocks_per_cu : occupancy_track_fast(A);
         if (D.resident_fast <= 0) D.resident_fast = 1;
       }
       const unsigned long long want = (count + kPoolBlockThreads - 1) / kPoolBlockThreads;
       unsigned long long resident = (unsigned long long)D.num_cus * (unsigned long long)D.resident_fast;
-      {  // spare workgroups (percent of the resident grid): see the kernel's prologue
-        const char* v = getenv("MCGPU_GRID_SPARE_PERCENT");
-        resident += resident * (unsigned long long)(v ? std::max(0, atoi(v)) : 0) / 100ULL;
-      }
-      {  // FAST scheduling knobs live in TrackCold; the environment may change them between launches (tuning sweeps)
-        auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-        TrackCold& ch = D.cold_host;
-        const int want5[5] = {env_int("MCGPU_THRESH_COMPTON", D.sched[0]), env_int("MCGPU_THRESH_RAYLEIGH", D.sched[1]), env_int("MCGPU_THRESH_NEW", D.sched[2]),
-                              std::max(1, env_int("MCGPU_FLYABLE_LOW", D.sched[3])), std::max(1, env_int("MCGPU_SWAP_BATCH", D.sched[4]))};
-        // bit 0: slots traded before flight, bit 1: before the Compton and tally/source services; bits 8-11: hold_q (sixteenths
-        // of the flying lanes that end a flight segment at the latest)
-        const int trade = env_int("MCGPU_SLOT_TRADE", 3) | ((env_int("MCGPU_HOLD_Q", 6) & 15) << 8);
-        if (ch.trade_slots != trade || ch.thresh_compton != want5[0] || ch.thresh_rayleigh != want5[1] || ch.thresh_new != want5[2] || ch.flyable_low != want5[3] ||
-            ch.swap_batch != want5[4]) {
-          ch.thresh_compton = want5[0]; ch.thresh_rayleigh = want5[1]; ch.thresh_new = want5[2]; ch.flyable_low = want5[3]; ch.swap_batch = want5[4];
-          ch.trade_slots = trade;
-          HIP_TRY(hipStreamSynchronize(stream));
-          HIP_TRY(hipMemcpy(D.cold, &ch, sizeof ch, hipMemcpyHostToDevice));
-        }
-      }
-      if (!D.work_counter) D.work_counter = D.put(std::vector<unsigned long long>((size_t)kNumCounters * kCounterStride, 0ULL));
+      resident += resident * (unsigned long long)D.knobs.grid_spare_percent / 100ULL;  // spare workgroups: see the kernel's prologue
       HIP_TRY(hipMemsetAsync(D.work_counter, 0, (size_t)kNumCounters * kCounterStride * 8, stream));
       A.work_counter = D.work_counter;
       if (mode == MCGPU_MODE_FAST_STATS) {
@@ -931,6 +964,17 @@ int mcgpu_set_fast_schedule(mcgpu_ctx* ctx, int thresh_compton, int thresh_rayle
           -2, "!!ERROR!! mcgpu_set_fast_schedule: thresholds are lane counts in 1..64");
   const int v[5] = {thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch};
   for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = v[k];
+  apply_schedule(ctx->dev);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_reload_env_knobs(mcgpu_ctx* ctx) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_reload_env_knobs: no device context");
+  read_env_knobs(ctx->dev);
+  ctx->dev.resident_fast = 0;  // MCGPU_BLOCKS_PER_CU may have changed: asked again at the next launch
+  apply_schedule(ctx->dev);
   return 0;
   ABI_END
 }
@@ -1032,6 +1076,7 @@ int mcgpu_format_projection(mcgpu_ctx* ctx, const void* image_dev, unsigned long
     HIP_TRY(hipHostMalloc((void**)&S.text_host, D.ascii_capacity, hipHostMallocNonCoherent));
     HIP_TRY(hipHostMalloc((void**)&S.rows_host, words * 8, hipHostMallocDefault));
     HIP_TRY(hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
   }
   AsciiArgs a;
   a.image = (const unsigned long long*)image_dev;
@@ -1043,6 +1088,7 @@ int mcgpu_format_projection(mcgpu_ctx* ctx, const void* image_dev, unsigned long
   a.flags = (unsigned int*)(S.rows_dev + 5 * nz + 1);
   HIP_TRY(launch_ascii_format(a, (hipStream_t)hip_stream));
   HIP_TRY(hipMemcpyAsync(S.rows_host, S.rows_dev, words * 8, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  HIP_TRY(hipEventRecord(S.ready, (hipStream_t)hip_stream));  // mcgpu_write_formatted_projection waits for it itself
   return 0;
   ABI_END
 }
@@ -1055,6 +1101,7 @@ int mcgpu_write_formatted_projection(mcgpu_ctx* ctx, int p, int slot, unsigned l
   DeviceModel::AsciiSlot& S = D.ascii[slot];
   require(S.text_dev != nullptr, -1, "!!ERROR!! mcgpu_write_formatted_projection: nothing was formatted in this slot");
   HIP_TRY(hipSetDevice(D.device_id));
+  HIP_TRY(hipEventSynchronize(S.ready));  // the row block (coherent pinned memory) and the text on the device are complete
   const int nz = ctx->host.detector[0].nz;
   const unsigned long long* rows = S.rows_host;
   const unsigned int flags = (unsigned int)rows[5 * nz + 1];
@@ -1311,6 +1358,7 @@ int mcgpu_set_geometry_arrays(mcgpu_ctx* ctx, const int n[3], const float spacin
       throw;
     }
     for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = old.sched[k];  // the tuned FAST schedule survives a geometry change
+    apply_schedule(ctx->dev);
     old.release();  // NB: the dose tallies belong to a geometry and restart from zero with the new one
   }
   ctx->host_voxels_stale = false;
@@ -1362,7 +1410,7 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
   g.sub_first = D.sub_first; g.brick_first = D.brick_first;
   g.sub = D.sub; g.bricks = D.bricks; g.code_of = D.code_of_dev; g.background = D.background;
   g.out = D.rebuild_out;
-  const bool allow_exterior = getenv("MCGPU_NO_EXTERIOR") == nullptr;
+  const bool allow_exterior = !D.knobs.no_exterior;
   HIP_TRY(launch_geometry_rebuild(g, frame, allow_exterior, nullptr));
   unsigned int out[17];
   HIP_TRY(hipMemcpy(out, D.rebuild_out, sizeof out, hipMemcpyDeviceToHost));  // waits for the kernels
@@ -1382,6 +1430,7 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
     HIP_TRY(hipMemcpy(D.woodcock, wood.data(), wood.size() * 4, hipMemcpyHostToDevice));
   }
   D.bricks_mixed = (int)out[14]; D.bricks_exterior = (int)out[15]; D.sub_mixed = (int)out[16];
+  const int had_exterior = D.has_exterior;
   D.has_exterior = out[15] > 0 ? 1 : 0;
   if (D.has_exterior) {
     const int k = D.brick_shift;
@@ -1391,8 +1440,12 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
       D.cold_host.objbox_lo[a] = D.objbox_lo[a];
       D.cold_host.objbox_hi[a] = D.objbox_hi[a];
     }
-    HIP_TRY(hipMemcpy(D.cold, &D.cold_host, sizeof D.cold_host, hipMemcpyHostToDevice));
+    // code 14 means "background outside the object box" (pack_codes_kernel): its palette slot must name the background
+    // even when the BASE geometry had no exterior (its object box spanned the whole brick grid) and the warp made one
+    D.brick_palette[14] = D.background;
+    D.cold_host.brick_palette[14] = D.background;
   }
+  if (D.has_exterior || had_exterior) HIP_TRY(hipMemcpy(D.cold, &D.cold_host, sizeof D.cold_host, hipMemcpyHostToDevice));
   ctx->host_voxels_stale = true;
   ctx->table_cache.clear();
   return 0;

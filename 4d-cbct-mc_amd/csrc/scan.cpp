@@ -19,6 +19,7 @@
 // devices (tests run two "devices" on one).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -331,9 +332,14 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     // reduce + finalize of projection j on device 0's stream, then hand it to the writer
     auto enqueue_reduce = [&](int j) {
       const int b = j & 1, t = single ? 0 : b;
-      {  // pinned buffer b is free once projection j-2 has been written
+      {  // pinned buffer b is free once projection j-2 has been written.  Formatter slot j % n_ascii was last used by
+         // projection j - n_ascii: that one must have been HANDED to its worker (the writer sets ascii_busy when it has
+         // written the projection's stacks, together with `written`) and the worker must be done.  With one slot the
+         // previous projection itself is the slot's last user, so `written >= j - 1` is not enough (it would let
+         // projection j be formatted over the text of j - 1 before j - 1 was even handed over).
+        const int handed = j - std::min(1, n_ascii - 1);
         std::unique_lock<std::mutex> lk(sh.mu);
-        sh.cv.wait(lk, [&] { return (sh.written >= j - 1 && !sh.ascii_busy[j % n_ascii]) || sh.abort; });
+        sh.cv.wait(lk, [&] { return (sh.written >= handed && !sh.ascii_busy[j % n_ascii]) || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
       HIP_OK(hipSetDevice(D[0].dev));

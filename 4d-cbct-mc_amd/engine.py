@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
-    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
 )
 
 
@@ -114,6 +114,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
     lib.mcgpu_write_voxel_binary.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+    lib.mcgpu_reload_env_knobs.argtypes = [vp]
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     if path is None:
         _lib = lib
@@ -288,6 +289,10 @@ class Context:
 
     def clear(self, image_dev_ptr: int, stream: int = 0):
         _check(self.lib.mcgpu_clear_image(self.h, C.c_void_p(image_dev_ptr), C.c_void_p(stream)))
+
+    def reload_env_knobs(self):
+        """Read the MCGPU_* tuning knobs of the environment again (they are otherwise read once, at creation)."""
+        _check(self.lib.mcgpu_reload_env_knobs(self.h))
 
     def scheduler_stats(self, reset: bool = True) -> dict:
         """Counters of "stats"-mode launches (diagnostic build): mean flying lanes per wave iteration etc."""

@@ -103,6 +103,12 @@ int mcgpu_scheduler_stats(mcgpu_ctx *ctx, unsigned long long *out8, int reset);
  * few percent between geometries.  mcgpu_run_scan picks among a few presets with short throw-away launches unless
  * MCGPU_THRESH_* / MCGPU_FLYABLE_LOW / MCGPU_SWAP_BATCH are set in the environment (those always win). */
 int mcgpu_set_fast_schedule(mcgpu_ctx *ctx, int thresh_compton, int thresh_rayleigh, int thresh_new, int flyable_low, int swap_batch);
+/* The tuning knobs of the environment (MCGPU_THRESH_*, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH, MCGPU_SLOT_TRADE,
+ * MCGPU_HOLD_Q, MCGPU_EXTERIOR_MODE, MCGPU_BLOCKS_PER_CU, MCGPU_GRID_SPARE_PERCENT, MCGPU_COMPAT_THRESH_*) are read ONCE, when
+ * the context's device model is built; mcgpu_launch_projection never reads the environment and never synchronises.  Tuning
+ * tools that change them in a live process call this to read them again (drains the device, re-uploads the parameter block).
+ * The reference has no counterpart: its launch shape is fixed by the input file (MC-GPU_v1.3.cu:823-841). */
+int mcgpu_reload_env_knobs(mcgpu_ctx *ctx);
 /* The same with the full counter set (up to 16): 8 = scheduling points, 9/10 = register<->LDS-slot exchange rounds /
  * lanes that bring a flying history in, 11 = scheduling points in drain mode. */
 int mcgpu_scheduler_stats_ex(mcgpu_ctx *ctx, unsigned long long *out, int capacity, int reset);
@@ -122,8 +128,10 @@ int mcgpu_write_projection(mcgpu_ctx *ctx, int p, const uint64_t *image_host, un
 /* report_image with the 1.4 M data lines formatted ON THE DEVICE (MC-GPU_v1.3.cu:2860-2904: four "%.8lf" numbers per pixel,
  * a blank line per detector row; exact decimal conversion in integer arithmetic, byte-identical to mcgpu_write_projection).
  * mcgpu_format_projection is asynchronous on `hip_stream`: it reads the device tally `image_dev` (before it is cleared) and
- * fills one of MCGPU_ASCII_SLOTS internal slots; once the stream has passed that point (event / synchronize), the host side
- * mcgpu_write_formatted_projection downloads the text with a copy engine and writes header + text + footer.  The scan driver
+ * fills one of MCGPU_ASCII_SLOTS internal slots and records an event behind it; the host side
+ * mcgpu_write_formatted_projection waits for that event, downloads the text with a copy engine and writes header + text +
+ * footer.  A tally with a value outside the formatter's range (>= 1e11 eV/cm^2 per history; unreachable for photon physics)
+ * makes it return -3 -- there is no host fallback on this route (the tally has been cleared by then).  The scan driver
  * cycles through the slots with one writer thread each, so the files of projections i - 2 .. i are written side by side
  * while i + 1 is tracked and formatted.  Different slots may be used from different threads at the same time. */
 #define MCGPU_ASCII_SLOTS 3

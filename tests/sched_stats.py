@@ -15,6 +15,7 @@ with eng.create(inp, device=0) as ctx:
             os.environ.pop(k, None)
         for k, v in zip(KEYS, [x for x in cfg.split(",") if x]):
             os.environ[k] = v
+        ctx.reload_env_knobs()
         ctx.run_projection(0, n, mode="fast", seed=42)  # warm
         _, secs, _ = ctx.run_projection(0, n, mode="fast", seed=42)
         img, secs_stats, done = ctx.run_projection(0, n, mode="stats", seed=42)

@@ -161,6 +161,51 @@ def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, 
 
 
 @pytest.mark.gpu
+def test_device_warp_that_creates_an_exterior_names_its_background(engine, tmp_path):
+    """A base geometry whose object box spans the whole brick grid (bone blocks in all eight corners: no EXTERIOR bricks, the
+    palette slot of brick code 14 is unset) and a respiratory state that pulls the object inward (the corners leave the
+    volume, a centre block is magnified): the device rebuild now codes the rim as EXTERIOR and must point code 14 at the
+    background (water) -- palette entry 0 is the corner's bone.  Same tallies as a fresh context on the warped voxel file."""
+    mats, spc = cases.material_files(), cases.spectrum_file()
+    g = cases.geometry.MCBoxGeometry(shape=(32, 32, 24), image_spacing=(10.0, 10.0, 10.0), material="h2o")
+    bone = cases.materials.material_number("bone_050")
+    for sx in (slice(0, 4), slice(28, 32)):
+        for sy in (slice(0, 4), slice(28, 32)):
+            for sz in (slice(0, 4), slice(20, 24)):
+                g.materials[sx, sy, sz] = bone
+                g.densities[sx, sy, sz] = 1.4
+    g.materials[14:18, 14:18, 10:14] = bone
+    g.densities[14:18, 14:18, 10:14] = 1.4
+    shape = g.materials.shape
+    grid = np.meshgrid(*[np.arange(n, dtype=np.float32) for n in shape], indexing="ij")
+    centre = [(n - 1) / 2.0 for n in shape]
+    field = np.stack([0.5 * (c - x) for x, c in zip(grid, centre)]).astype(np.float32)  # out[x] = base[(x + c) / 2]
+    kw = dict(n_projections=2, angle_between_projections=70.0, n_histories=200_000, **cases.SMALL_DET)
+    base = cases.simulation.MCSimulation(g, mats, spc, **kw).prepare_simulation(tmp_path / "base")
+    air = cases.materials.material_number("air")
+    wm, wd = warp_ref.warp_nearest(g.materials, g.densities, field, air, cases.materials.MATERIALS_125KEV["air"])
+    assert (wm[:8, :8, :6] != bone).all() and (wm == bone).sum() > 64  # corners gone, centre block magnified
+    warped = cases.simulation.MCSimulation(cases.geometry.MCGeometry(wm, wd, g.image_spacing), mats, spc, **kw).prepare_simulation(tmp_path / "warped")
+    with engine.create(base, device=0) as dev, engine.create(warped, device=0) as ref:
+        assert dev.geti("bricks_exterior") == 0 and ref.geti("bricks_exterior") > 0
+        dev.warp_geometry(field, frame="geometry")
+        assert np.array_equal(dev.host_table("voxel_mat_dens"), ref.host_table("voxel_mat_dens"))
+        for key in ("bricks_mixed", "bricks_exterior", "brick_shift", "brick_count"):
+            assert dev.geti(key) == ref.geti(key), key
+        for p in range(2):
+            a, _, _ = dev.run_projection(p, 400_000, mode="fast", seed=9)
+            b, _, _ = ref.run_projection(p, 400_000, mode="fast", seed=9)
+            assert np.array_equal(a, b) and a.sum() > 0
+        # and back: the identity field restores the base, whose exterior is empty again
+        dev.warp_geometry(np.zeros_like(field), frame="geometry")
+        assert dev.geti("bricks_exterior") == 0
+        with engine.create(base, device=0) as fresh:
+            a, _, _ = dev.run_projection(1, 300_000, mode="fast", seed=3)
+            b, _, _ = fresh.run_projection(1, 300_000, mode="fast", seed=3)
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("phantom", ["slab", "cirs76"])
 def test_4d_scan_equals_per_state_file_based_runs(engine, tmp_path, phantom):
     """The resident 4-D driver (BASELINE config 5 at reduced size: CIRS phantom + correspondence model + respiratory signal)

@@ -143,6 +143,7 @@ def test_fast_image_is_independent_of_the_schedule(gpu_engine, case_dir, monkeyp
                       {"MCGPU_THRESH_COMPTON": "7", "MCGPU_THRESH_NEW": "50", "MCGPU_FLYABLE_LOW": "40", "MCGPU_SWAP_BATCH": "3"}):
             for k, v in knobs.items():
                 monkeypatch.setenv(k, v)
+            ctx.reload_env_knobs()
             for i, p in enumerate((0, 2)):
                 for rep in range(2):
                     img = ctx.run_projection(p, n, mode="fast", seed=11)[0]

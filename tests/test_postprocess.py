@@ -183,6 +183,27 @@ def test_device_finalize_and_scan_pipeline(engine, case_dir, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("writers", [1, 2])
+def test_scan_ascii_files_with_few_formatter_slots(engine, case_dir, tmp_path, monkeypatch, writers):
+    """MCGPU_ASCII_WRITERS=1: every projection is formatted into the ONE slot its predecessor used -- the projection loop
+    must wait until that predecessor has been handed to the slot's worker and written (scan.cpp: enqueue_reduce).  The files
+    of the scan equal the host formatter's for the same tallies."""
+    n_hist = 200_000
+    monkeypatch.setenv("MCGPU_ASCII_WRITERS", str(writers))
+    with engine.create(case_dir("catphan64_ct", n_projections=8, angle_between_projections=45.0), device=0) as ctx:
+        out = tmp_path / "scan"
+        out.mkdir()
+        rep = ctx.run_scan(mode="fast", histories=n_hist, crop_nx=128, write_ascii=True, write_stacks=False, output_folder=out)
+        assert rep["projections"] == 8
+        data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]
+        for p in range(8):
+            img = ctx.run_projection(p, n_hist, mode="fast", seed=ctx.geti("seed"))[0]
+            ref_file = tmp_path / f"ref_{p}"
+            ctx.write_projection(p, img, n_hist, file_name=str(ref_file))
+            assert data(ctx.projection_file_name(p)) == data(ref_file), p
+
+
+@pytest.mark.gpu
 def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_path):
     """mcgpu_run_scan_multi: three contexts (here on one device) shard the histories, the first one's device reduces the
     tallies peer to peer, finalizes and writes; stacks and ASCII files equal the single-context scan bit for bit."""

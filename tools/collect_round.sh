@@ -2,8 +2,12 @@
 # End-of-round measurement set (GPU box, repo root): PMC passes first (their summaries are what the bench lines quote as
 # roofline.traffic, stamped with the kernel's source hash), then bench lines, rocprofv3 kernel stats -> gpurun_out/<tag>/
 # Usage: bash tools/collect_round.sh r02
-TAG=${1:-r02}; OUT=gpurun_out/$TAG; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+TAG=${1:-r03}; OUT=gpurun_out/$TAG
+export TMPDIR=/tmp
+cd "$ROOT"
+mkdir -p "$OUT"
 LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat"
 bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json; cp $OUT/pmc/summary.json profiles/pmc_summary_latest.json
 for wl in thorax cirs; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done

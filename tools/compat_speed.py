@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import cases
 eng = cases.pkg.engine
 with eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0) as ctx:

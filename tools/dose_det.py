@@ -1,6 +1,6 @@
 import sys, numpy as np, tempfile
 from pathlib import Path
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import cases
 eng = cases.pkg.engine
 inp = cases.build_case("catphan64_dose", Path(tempfile.mkdtemp()))

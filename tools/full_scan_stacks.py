@@ -1,6 +1,6 @@
 """The whole bench scan (894 projections of 1e8 histories) with the three MetaImage stacks written (8.4 GB): end-to-end time."""
 import sys, time, shutil
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import cases
 from pathlib import Path
 eng = cases.pkg.engine

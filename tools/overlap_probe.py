@@ -1,7 +1,7 @@
 """What does work on a second stream cost the persistent tracking kernel?  (scan driver / RCCL-overlap design input)
 For each variant: 12 projections; a side operation is issued on another stream `delay_us` after the launch."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import numpy as np, torch, cases
 eng = cases.pkg.engine
 ctx = eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0)
@@ -50,6 +50,7 @@ def before(name, op, n_ops=1):
 import os
 for spare in (0, 25, 100):
     os.environ["MCGPU_GRID_SPARE_PERCENT"] = str(spare)
+    ctx.reload_env_knobs()
     print("spare percent", spare)
     variant("alone", None, 0)
     before("256 MB add_", lambda: dev_big.add_(1.0))

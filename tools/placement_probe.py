@@ -1,7 +1,7 @@
 """Where do the persistent tracking kernel's waves land, alone vs. launched while another kernel is running?
 Diagnostic (stats) build: per wave {HW_ID, XCC_ID, first/last clock (100 MHz)}; see track_pool.inc."""
 import sys, ctypes as C, collections
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import numpy as np, torch, cases
 eng = cases.pkg.engine
 ctx = eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0)

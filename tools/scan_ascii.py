@@ -1,6 +1,6 @@
 """Scan with the reference's ASCII projection files written (63 MB of text per projection): writer time per projection."""
 import sys, time, shutil
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import cases
 from pathlib import Path
 eng = cases.pkg.engine

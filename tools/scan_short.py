@@ -1,6 +1,6 @@
 """Short scan (no output files) for timeline profiling of the scan driver: python tools/scan_short.py [n_projections]."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import cases
 from pathlib import Path
 eng = cases.pkg.engine

@@ -1,7 +1,8 @@
 """Kernel-time sweep of the FAST scheduler knobs on the bench workload (GPU).
 usage: tune.py "tC,tR,tN,flyable_low,swap_batch" ...   (5 launches of 1e8 histories each, mean kernel ms)"""
 import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch, cases
 eng = cases.pkg.engine
 KEYS = ("MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH")
@@ -20,6 +21,7 @@ for cfg in sys.argv[1:]:
         os.environ.pop(k, None)
     for k, v in zip(KEYS, [x for x in cfg.split(",") if x]):
         os.environ[k] = v
+    ctx.reload_env_knobs()
     ms = []
     for i in range(7):
         ctx.clear(image.data_ptr(), stream)
