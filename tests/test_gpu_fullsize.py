@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import cases
+import golden_util as gu
 import oracle_lib as ol
 import parity
 
@@ -196,3 +197,17 @@ def test_cirs_full_size_respiratory_state_on_the_device(cirs_full):
         ctx.warp_geometry(np.zeros_like(field), frame="geometry")
     assert np.array_equal(ctx.host_table("voxel_mat_dens", "<f4"), base_vox)
     assert np.array_equal(ctx.host_table("mfp_woodcock"), base_wood)
+
+
+# ------------------------------------------------------------------ the host tables behind all of the above
+@pytest.mark.parametrize("workload", ["catphan", "thorax", "cirs"])
+def test_bench_size_host_tables_equal_the_reference_parse(workload, request):
+    """Every parity test above feeds the oracle the engine's host tables (tests/parity.py), loaded through the binary sidecar
+    like bench.py loads them.  Here those tables hash to what the REFERENCE's own load_voxels / load_material / trajectory
+    code made of the text files of the same workload (134 M voxel lines for the Catphan): tests/golden/fullsize_ref_pin.json,
+    written by oracle/gen_fullsize_pin.py from oracle/_ref."""
+    ctx = request.getfixturevalue({"catphan": "catphan512", "thorax": "thorax512", "cirs": "cirs_full"}[workload])
+    got, used = gu.fullsize_digests(ctx)
+    pin = gu.fullsize_pin(workload)
+    assert used == pin["used_materials"]
+    assert got == pin["sha256"], {k: (got[k][:12], pin["sha256"][k][:12]) for k in got if got[k] != pin["sha256"][k]}

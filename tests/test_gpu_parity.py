@@ -152,6 +152,58 @@ def test_fast_image_is_independent_of_the_schedule(gpu_engine, case_dir, monkeyp
                 monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("case", ["thorax64", "tissue22"])
+def test_fast_image_is_independent_of_slot_trading_segment_rule_and_brick_levels(gpu_engine, case_dir, monkeypatch, case):
+    """Round-2 scheduler and lookup features, same statement as above -- identical tally WORDS required:
+    slot trading (MCGPU_SLOT_TRADE 0..3: lanes re-point their LDS slots with six cross-lane permutes, the place where a
+    history could be dropped or duplicated), the segment-end rule (MCGPU_HOLD_Q), the second brick level (MCGPU_SUB_BRICKS)
+    and the size of the first one (MCGPU_MAX_BRICKS: coarser bricks turn homogeneous lookups into mixed ones and move the
+    object box).  Tissue volumes, where mixed bricks dominate."""
+    n, p = 1_200_000, 1
+    with gpu_engine.create(case_dir(case), device=0) as ctx:
+        ref, _, done = ctx.run_projection(p, n, mode="fast", seed=21)
+        assert done == n and ref.sum() > 0
+        for trade in (0, 1, 2, 3):
+            for hold_q in (0, 6, 15):
+                monkeypatch.setenv("MCGPU_SLOT_TRADE", str(trade))
+                monkeypatch.setenv("MCGPU_HOLD_Q", str(hold_q))
+                ctx.reload_env_knobs()
+                img = ctx.run_projection(p, n, mode="fast", seed=21)[0]
+                assert np.array_equal(img, ref), (trade, hold_q)
+        monkeypatch.delenv("MCGPU_SLOT_TRADE")
+        monkeypatch.delenv("MCGPU_HOLD_Q")
+    # The brick SIZE moves the object box, and with it the region the exterior hop crosses analytically: a different (equally
+    # valid) use of the random numbers.  With the hop off, a lookup returns the same (material, density) whatever the two
+    # brick levels look like, so the tallies may not move at all; with it on, the second level alone may not move them.
+    seen, compat_ref, plain_ref = set(), None, None
+    for no_exterior in (False, True):
+        if no_exterior:
+            monkeypatch.setenv("MCGPU_NO_EXTERIOR", "1")
+        for sub in ("0", "1"):
+            for max_bricks in ((None, "300", "40") if no_exterior else (None,)):
+                monkeypatch.setenv("MCGPU_SUB_BRICKS", sub)
+                if max_bricks:
+                    monkeypatch.setenv("MCGPU_MAX_BRICKS", max_bricks)
+                else:
+                    monkeypatch.delenv("MCGPU_MAX_BRICKS", raising=False)
+                with gpu_engine.create(case_dir(case), device=0) as ctx:
+                    assert (ctx.geti("bricks_exterior") == 0) == no_exterior
+                    if max_bricks:
+                        assert ctx.geti("brick_count") <= int(max_bricks)
+                    img = ctx.run_projection(p, n, mode="fast", seed=21)[0]
+                    if no_exterior:
+                        seen.add((ctx.geti("brick_shift"), ctx.geti("bricks_mixed"), ctx.geti("sub_bricks_mixed")))
+                        plain_ref = img if plain_ref is None else plain_ref
+                        assert np.array_equal(img, plain_ref) and img.sum() > 0, (sub, max_bricks)
+                    else:
+                        assert np.array_equal(img, ref), (sub, max_bricks)
+                    # COMPAT reads the same brick grid (no hop): its tallies may not move either
+                    a = ctx.run_projection(p, 256, mode="compat", seed=5, hpt=50)[0]
+                    compat_ref = a if compat_ref is None else compat_ref
+                    assert np.array_equal(a, compat_ref) and a.sum() > 0, (no_exterior, sub, max_bricks)
+    assert len({s[0] for s in seen}) == 3  # three brick sizes were really exercised
+
+
 def test_fast_cross_section_brackets_decide_like_the_exact_table(gpu_engine, case_dir, monkeypatch):
     """The flight step decides most virtual/real tests from the LDS brackets of the total cross section (track_pool.inc:
     flight_step) and fetches the exact value only inside the bracket: the decisions -- hence every tally word -- must be

@@ -102,3 +102,19 @@ def test_ascii_projection_writer_matches_report_image(name, case_dir, engine, tm
         norm = (1.0 / 100.0) * float(np.float32(g["detector_data"].view("<f4")[19])) * float(np.float32(g["detector_data"].view("<f4")[20])) / (nb * hpt)
         back = np.rint(arr / norm).astype(np.uint64)
         assert np.array_equal(back.transpose(2, 0, 1).reshape(-1), img)
+
+
+def test_bench_size_cirs_tables_equal_the_reference_parse(engine, tmp_path):
+    """The bench-size CIRS workload as bench.py loads it (binary sidecar geometry.voxbin) against what the reference's own
+    load_voxels / load_material made of the TEXT files (tests/golden/fullsize_ref_pin.json, oracle/gen_fullsize_pin.py):
+    closes the common-mode path of the GPU parity tests, which feed the oracle the engine's host tables.  The 512^3 Catphan
+    and the thorax are checked the same way in tests/test_gpu_fullsize.py (their fixtures take minutes to write)."""
+    import bench
+    import golden_util as gu
+    inp = bench.build_workload(tmp_path, "cirs", int(1e8), 894, engine)
+    assert (tmp_path / "geometry.voxbin").exists()
+    with engine.create(inp, device=-1) as ctx:
+        got, used = gu.fullsize_digests(ctx)
+    pin = gu.fullsize_pin("cirs")
+    assert used == pin["used_materials"]
+    assert got == pin["sha256"]

@@ -1,0 +1,187 @@
+// ipc_probe.hip -- which cross-process mechanisms does this pool offer for the N > 1 tally exchange?  (dev tool, GPU)
+//
+// Two processes on ONE device (forked before any HIP call; each initialises HIP itself):
+//   owner  : hipMalloc landing buffer -> hipIpcGetMemHandle; interprocess event "consumed" -> hipIpcGetEventHandle
+//   pusher : opens both; fills a source tally; copies it into the landing buffer with (a) plain hipMemcpyAsync D2D,
+//            (b) hipMemcpyDeviceToDeviceNoCU (copy engine); records its own interprocess event "pushed"
+//   owner  : hipStreamWaitEvent on the opened "pushed" event, then checks the pattern on the device.
+// Every wait has a way out: the pusher always records its event, and both sides exchange plain pipe messages first, so a
+// refused API shows up as an error line, never as a hang.  Run under `timeout 120`.
+//   hipcc --offload-arch=gfx950 -O2 -o tools/micro/ipc_probe tools/micro/ipc_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#define CK(expr)                                                                              \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) { printf("[%s] %s -> %s\n", who, #expr, hipGetErrorString(e_)); fflush(stdout); ok = false; } \
+  } while (0)
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+__global__ void fill(unsigned long long* p, size_t n, unsigned long long v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v + i;
+}
+__global__ void check(const unsigned long long* p, size_t n, unsigned long long v, unsigned int* bad) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (p[i] != v + i) atomicAdd(bad, 1u);
+}
+// a busy kernel to see whether a copy disturbs compute: dependent FMAs, every CU occupied
+__global__ void spin(float* out, int iters) {
+  float a = threadIdx.x * 1e-3f, b = 1.0001f;
+  for (int i = 0; i < iters; ++i) a = fmaf(a, b, 1e-6f);
+  if (a == 123.456f) out[0] = a;
+}
+
+struct Msg {
+  hipIpcMemHandle_t mem;
+  hipIpcEventHandle_t ev;
+  int mem_ok, ev_ok;
+};
+
+int main() {
+  const size_t words = (size_t)4 * 1848 * 768, bytes = words * 8;
+  int to_pusher[2], to_owner[2];
+  if (pipe(to_pusher) || pipe(to_owner)) return 1;
+  const pid_t pid = fork();
+  bool ok = true;
+  if (pid != 0) {  // ---------------- owner
+    const char* who = "owner";
+    unsigned long long* landing = nullptr;
+    hipStream_t s;
+    hipEvent_t consumed = nullptr, pushed = nullptr;
+    Msg m;
+    memset(&m, 0, sizeof m);
+    CK(hipSetDevice(0));
+    CK(hipStreamCreate(&s));
+    CK(hipMalloc((void**)&landing, bytes));
+    CK(hipMemset(landing, 0, bytes));
+    hipError_t e = hipIpcGetMemHandle(&m.mem, landing);
+    m.mem_ok = (e == hipSuccess);
+    printf("[owner] hipIpcGetMemHandle: %s\n", hipGetErrorString(e));
+    e = hipEventCreateWithFlags(&consumed, hipEventDisableTiming | hipEventInterprocess);
+    printf("[owner] hipEventCreateWithFlags(interprocess): %s\n", hipGetErrorString(e));
+    if (e == hipSuccess) {
+      e = hipIpcGetEventHandle(&m.ev, consumed);
+      printf("[owner] hipIpcGetEventHandle: %s\n", hipGetErrorString(e));
+    }
+    m.ev_ok = (e == hipSuccess);
+    fflush(stdout);
+    if (write(to_pusher[1], &m, sizeof m) != (ssize_t)sizeof m) return 1;
+    Msg r;
+    if (read(to_owner[0], &r, sizeof r) != (ssize_t)sizeof r) return 1;  // the pusher has pushed and recorded its event
+    if (r.ev_ok) {
+      e = hipIpcOpenEventHandle(&pushed, r.ev);
+      printf("[owner] hipIpcOpenEventHandle(pushed): %s\n", hipGetErrorString(e));
+      if (e == hipSuccess) {
+        CK(hipStreamWaitEvent(s, pushed, 0));
+        printf("[owner] hipStreamWaitEvent on the opened event: enqueued\n");
+      }
+    }
+    unsigned int* bad = nullptr;
+    CK(hipMalloc((void**)&bad, 4));
+    CK(hipMemsetAsync(bad, 0, 4, s));
+    hipLaunchKernelGGL(check, dim3(1024), dim3(256), 0, s, landing, words, 7000ULL, bad);
+    unsigned int hb = 99;
+    CK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    printf("[owner] landing buffer after the push: %u wrong words of %zu\n", hb, words);
+    if (consumed) CK(hipEventRecord(consumed, s));
+    int status = 0;
+    waitpid(pid, &status, 0);
+    printf("[owner] pusher exit status %d; owner ok=%d\n", WEXITSTATUS(status), (int)ok);
+    return ok && hb == 0 ? 0 : 2;
+  }
+  // ---------------- pusher
+  const char* who = "pusher";
+  Msg m;
+  if (read(to_pusher[0], &m, sizeof m) != (ssize_t)sizeof m) return 1;
+  CK(hipSetDevice(0));
+  hipStream_t s, c;
+  CK(hipStreamCreate(&s));
+  CK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+  unsigned long long *src = nullptr, *dst = nullptr, *local = nullptr;
+  float* junk = nullptr;
+  CK(hipMalloc((void**)&src, bytes));
+  CK(hipMalloc((void**)&local, bytes));
+  CK(hipMalloc((void**)&junk, 4));
+  hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, s, src, words, 7000ULL);
+  CK(hipStreamSynchronize(s));
+  Msg r;
+  memset(&r, 0, sizeof r);
+  if (m.mem_ok) {
+    hipError_t e = hipIpcOpenMemHandle((void**)&dst, m.mem, hipIpcMemLazyEnablePeerAccess);
+    printf("[pusher] hipIpcOpenMemHandle: %s\n", hipGetErrorString(e));
+    if (e != hipSuccess) dst = nullptr;
+  }
+  auto time_copy = [&](const char* label, void* d, hipMemcpyKind kind, bool with_spin) {
+    hipEvent_t k0, k1;
+    CK(hipEventCreate(&k0)); CK(hipEventCreate(&k1));
+    for (int rep = 0; rep < 3; ++rep) {
+      if (with_spin) {
+        CK(hipEventRecord(k0, s));
+        hipLaunchKernelGGL(spin, dim3(256 * 8), dim3(1024), 0, s, junk, 400000);
+        CK(hipEventRecord(k1, s));
+      }
+      const double t0 = now();
+      CK(hipMemcpyAsync(d, src, bytes, kind, c));
+      CK(hipStreamSynchronize(c));
+      const double dt = now() - t0;
+      float kms = 0.f;
+      if (with_spin) { CK(hipStreamSynchronize(s)); CK(hipEventElapsedTime(&kms, k0, k1)); }
+      if (rep > 0) printf("[pusher] %-42s %6.2f ms = %5.1f GB/s%s", label, dt * 1e3, bytes / dt / 1e9, with_spin ? "" : "\n");
+      if (rep > 0 && with_spin) printf("   busy kernel beside it: %.2f ms\n", kms);
+    }
+  };
+  {
+    hipEvent_t k0, k1;
+    CK(hipEventCreate(&k0)); CK(hipEventCreate(&k1));
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(k0, s));
+      hipLaunchKernelGGL(spin, dim3(256 * 8), dim3(1024), 0, s, junk, 400000);
+      CK(hipEventRecord(k1, s));
+      CK(hipStreamSynchronize(s));
+      float kms = 0.f;
+      CK(hipEventElapsedTime(&kms, k0, k1));
+      if (rep > 0) printf("[pusher] busy kernel alone: %.2f ms\n", kms);
+    }
+  }
+  time_copy("local D2D, default", local, hipMemcpyDeviceToDevice, false);
+  time_copy("local D2D, NoCU (copy engine)", local, hipMemcpyDeviceToDeviceNoCU, false);
+  time_copy("local D2D, default, beside a busy kernel", local, hipMemcpyDeviceToDevice, true);
+  time_copy("local D2D, NoCU, beside a busy kernel", local, hipMemcpyDeviceToDeviceNoCU, true);
+  if (dst) {
+    time_copy("IPC-mapped D2D, default", dst, hipMemcpyDeviceToDevice, false);
+    time_copy("IPC-mapped D2D, NoCU (copy engine)", dst, hipMemcpyDeviceToDeviceNoCU, false);
+    time_copy("IPC-mapped D2D, NoCU, beside a busy kernel", dst, hipMemcpyDeviceToDeviceNoCU, true);
+  } else {
+    printf("[pusher] no IPC mapping: nothing pushed\n");
+  }
+  hipEvent_t pushed = nullptr;
+  hipError_t e = hipEventCreateWithFlags(&pushed, hipEventDisableTiming | hipEventInterprocess);
+  if (e == hipSuccess) {
+    CK(hipEventRecord(pushed, c));
+    e = hipIpcGetEventHandle(&r.ev, pushed);
+    printf("[pusher] hipIpcGetEventHandle(pushed): %s\n", hipGetErrorString(e));
+  } else {
+    printf("[pusher] interprocess event: %s\n", hipGetErrorString(e));
+  }
+  r.ev_ok = (e == hipSuccess);
+  CK(hipStreamSynchronize(c));
+  fflush(stdout);
+  if (write(to_owner[1], &r, sizeof r) != (ssize_t)sizeof r) return 1;
+  if (m.ev_ok) {
+    hipEvent_t consumed = nullptr;
+    e = hipIpcOpenEventHandle(&consumed, m.ev);
+    printf("[pusher] hipIpcOpenEventHandle(consumed): %s\n", hipGetErrorString(e));
+  }
+  if (dst) CK(hipIpcCloseMemHandle(dst));
+  fflush(stdout);
+  return ok ? 0 : 3;
+}
