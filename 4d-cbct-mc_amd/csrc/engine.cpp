@@ -1014,6 +1014,16 @@ int mcgpu_clear_image(mcgpu_ctx* ctx, void* image_dev, void* hip_stream) {
   ABI_END
 }
 
+int mcgpu_copy_to_host(mcgpu_ctx* ctx, const void* src_dev, void* dst_host, size_t bytes, void* hip_stream) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && src_dev && dst_host, -1, "!!ERROR!! mcgpu_copy_to_host: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  return 0;
+  ABI_END
+}
+
 int mcgpu_run_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned long long first, unsigned long long count, int hpt,
                          uint64_t* image_host, double* kernel_seconds, unsigned long long* histories_done) {
   ABI_BEGIN

@@ -34,7 +34,27 @@ __global__ __launch_bounds__(256) void accumulate_kernel(unsigned long long* __r
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
+// dst += src[0] + ... + src[n-1] in ONE pass (tally exchange, exchange.cpp): every word of every source is read once, the
+// destination is read and written once -- (n + 2) x 45 MB instead of the 3n x 45 MB of n separate adds.  16-byte accesses.
+__global__ __launch_bounds__(256) void accumulate_many_kernel(unsigned long long* __restrict__ dst, const unsigned long long* const* __restrict__ src, int n, size_t pairs) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 acc = reinterpret_cast<ulonglong2*>(dst)[i];
+    for (int k = 0; k < n; ++k) {
+      const ulonglong2 v = reinterpret_cast<const ulonglong2*>(src[k])[i];
+      acc.x += v.x; acc.y += v.y;
+    }
+    reinterpret_cast<ulonglong2*>(dst)[i] = acc;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_accumulate_many(unsigned long long* dst, const unsigned long long* const* src, int n, size_t words, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (words & 1) return hipErrorInvalidValue;  // tallies are 4 planes of pixels: always even
+  hipLaunchKernelGGL(accumulate_many_kernel, dim3(4096), dim3(256), 0, stream, dst, src, n, words / 2);
+  return hipGetLastError();
+}
 
 hipError_t launch_accumulate(unsigned long long* dst, const unsigned long long* src, size_t words, hipStream_t stream) {
   hipLaunchKernelGGL(accumulate_kernel, dim3(2048), dim3(256), 0, stream, dst, src, words);

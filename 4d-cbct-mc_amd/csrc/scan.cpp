@@ -2,26 +2,29 @@
 // as a device/host pipeline, written on top of the engine's own C ABI.
 //
 // Reference flow per projection, all on one host thread per rank: kernel -> D2H of the 45 MB tally -> MPI_Reduce to rank 0
-// (:1019) -> ~0.9 s of fprintf -> re-zero.  Here every device has ONE stream and everything a device does is ordered on it:
-//   peer g > 0 : track kernel for its shard of projection i -> push of its tally into a landing buffer on device 0
-//                (xGMI, one of two per peer) -> clear the tally
-//   device 0   : track kernel for its shard of projection i (tally buffer i & 1)
-//                -> REDUCE of projection i - 1: integer adds of the landed peer tallies -> [u64 copy to pinned memory, only
-//                when the ASCII files are wanted] -> finalize kernel (float32 planes + clears the tally) -> copy of the
-//                planes (9 MB) to one of two pinned buffers -> event
-//   writer thread : waits on the event, appends the planes to the three MetaImage stacks, formats the ASCII file.
-// The one-projection lag means device 0 never waits for a push (it had a whole kernel's time to land), and nothing ever
-// runs BESIDE a tracking launch: a kernel that is still resident while the persistent tracking grid is dispatched
-// fragments the CUs' register files for that whole launch (144 of 256 CUs then hold one workgroup instead of two:
-// 9.2 -> 12.5 ms, tools/placement_probe.py), so a separate "reduce stream" is slower than no overlap.
-// With one device the lag is zero and there is a single tally buffer (finalize takes 20 us between two 9 ms kernels).
+// (:1019) -> ~0.9 s of fprintf -> re-zero.  Here every device has ONE tracking stream and everything it does is ordered on it;
+// the sum of the per-device tallies is the tally exchange of exchange.cpp (the same code bench.py's ranks run, here between
+// contexts of one process):
+//   every device : begin(i) -> track kernel for its shard of projection i -> submit(i): devices that do not own projection i
+//                  push their tally to the owner with a copy engine while projection i + 1 is tracked
+//   owner of i-1 : collect(i - 1) behind its kernel i: one fused add of the landed tallies -> [ASCII text formatted on the
+//                  device, only when the files are wanted] -> finalize kernel (float32 planes) -> copy of the planes (9 MB)
+//                  to one of two pinned buffers -> event
+//   writer thread : waits on the event, appends the planes to the three MetaImage stacks, hands the ASCII text to its worker.
+// The owner rotates over the devices (projection i belongs to device i mod N; MCGPU_EXCHANGE_POLICY=0: always the first
+// device, the reference's root): the only work that is exposed on a tracking stream -- the fused add, finalize -- is spread
+// evenly, and so are the xGMI links.  The one-projection lag means no owner ever waits for a push (it had a whole kernel's
+// time to land), and nothing ever runs BESIDE a tracking launch: a kernel that is still resident while the persistent tracking
+// grid is dispatched fragments the CUs' register files for that whole launch (144 of 256 CUs then hold one workgroup instead
+// of two: 9.2 -> 12.5 ms, tools/placement_probe.py).  With one device the lag is zero.
 // History sharding keeps per-history RNG streams and integer tallies, so the result is identical for any number of
-// devices (tests run two "devices" on one).
+// devices (tests run several "devices" on one).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,10 +34,6 @@
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
-
-namespace mcgpu {
-hipError_t launch_accumulate(unsigned long long* dst, const unsigned long long* src, size_t words, hipStream_t stream);  // finalize.hip
-}
 
 namespace {
 
@@ -61,9 +60,9 @@ struct DeviceLane {  // per device
   mcgpu_ctx* ctx = nullptr;
   int dev = -1;
   hipStream_t stream = nullptr;
-  void* image[2] = {nullptr, nullptr};         // tally buffers (device 0 of a multi-device scan uses both, everyone else [0])
-  void* landing[2] = {nullptr, nullptr};       // peers: on device 0, where this peer's tally of projection i lands (i & 1)
-  hipEvent_t pushed[2] = {nullptr, nullptr};   // peers: the push into landing[b] has finished (recorded on the peer's stream)
+  mcgpu_exchange* x = nullptr;                 // this device's end of the tally exchange (owns the tally buffers)
+  void* planes_dev[2] = {nullptr, nullptr};    // float32 planes of the projections this device owns
+  hipEvent_t done[2] = {nullptr, nullptr};     // planes of pinned buffer b are on the host (system-scope release)
   unsigned long long lo = 0, hi = 0;           // shard of the units of every projection
 };
 
@@ -74,11 +73,10 @@ extern "C" void mcgpu_set_last_error_(const char* message);  // engine.cpp (not 
 extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
   if (!ctxs || n_ctx < 1 || !opt || !ctxs[0]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
   std::vector<DeviceLane> D((size_t)n_ctx);
-  void* planes_dev[2] = {nullptr, nullptr};
   float* planes_host[2] = {nullptr, nullptr};
   uint64_t* image_host[2] = {nullptr, nullptr};
-  hipEvent_t done[2] = {nullptr, nullptr};
-  hipEvent_t consumed[2] = {nullptr, nullptr};  // device 0 has added the landing buffers b of all peers
+  void* probe_image = nullptr;  // tally of the throw-away launches (time calibration, preset choice)
+  std::vector<unsigned char> mailboxes;  // host region of the exchange (contexts of one process: plain memory)
   mcgpu_stack* stacks[3] = {nullptr, nullptr, nullptr};
   std::thread writer;
   struct Shared {
@@ -92,6 +90,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     // to ONE file do not scale with threads -- they serialise on its inode lock -- writes to different files do)
     bool ascii_busy[kAsciiSlots] = {};
     int ascii_p[kAsciiSlots] = {};
+    mcgpu_ctx* ascii_ctx[kAsciiSlots] = {};  // the context (device) that formatted the slot's text
     double ascii_seconds[kAsciiSlots] = {};
     bool ascii_quit = false;
   } sh;
@@ -157,35 +156,34 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     }
 
     // ---- device resources
-    const unsigned int pinned_flags = getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent;
+    // pinned buffers are read by the writer thread and filled from whichever device owns the projection: portable
+    const unsigned int pinned_flags = (getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent) | hipHostMallocPortable;
     const bool ascii_on_host = getenv("MCGPU_ASCII_HOST") != nullptr;  // A/B: the threaded host formatter of report.cpp
     if (const char* w = getenv("MCGPU_ASCII_WRITERS")) n_ascii = std::min(std::max(atoi(w), 1), kAsciiSlots);
     const bool single = (n_ctx == 1);
+    int policy = MCGPU_EXCHANGE_LOCAL | MCGPU_EXCHANGE_ROTATE;
+    if (const char* v = getenv("MCGPU_EXCHANGE_POLICY")) policy = MCGPU_EXCHANGE_LOCAL | (atoi(v) ? MCGPU_EXCHANGE_ROTATE : 0);
+    mailboxes.assign(mcgpu_exchange_shared_bytes(n_ctx), 0);
+    void* const mailbox_region = mailboxes.data();
     for (int g = 0; g < n_ctx; ++g) {
       HIP_OK(hipSetDevice(D[g].dev));
       HIP_OK(hipStreamCreate(&D[g].stream));
-      for (int b = 0; b < ((g == 0 && !single) ? 2 : 1); ++b) {
-        HIP_OK(hipMalloc(&D[g].image[b], words * 8));
-        HIP_OK(hipMemsetAsync(D[g].image[b], 0, words * 8, D[g].stream));
-      }
-      if (g > 0)
-        for (int b = 0; b < 2; ++b) HIP_OK(hipEventCreateWithFlags(&D[g].pushed[b], hipEventDisableTiming));
+      ABI_OK(mcgpu_exchange_create(D[g].dev, g, n_ctx, words, policy, mailbox_region, &D[g].x));
     }
+    for (int g = 0; g < n_ctx; ++g)
+      for (int h = 0; h < n_ctx; ++h)
+        if (g != h) ABI_OK(mcgpu_exchange_connect_local(D[g].x, D[h].x));
     HIP_OK(hipSetDevice(D[0].dev));
-    hipStream_t const s0 = D[0].stream;
-    for (int b = 0; b < 2 && !single; ++b) {
-      HIP_OK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
-      for (int g = 1; g < n_ctx; ++g) HIP_OK(hipMalloc(&D[g].landing[b], words * 8));
-    }
     if (by_time) {
       const unsigned long long probe = 4000000ULL;
       const unsigned long long probe_units = mode == MCGPU_MODE_COMPAT ? (probe + (unsigned long long)hpt - 1) / (unsigned long long)hpt : probe;
       float ms = 0.f;
+      if (!probe_image) HIP_OK(hipMalloc(&probe_image, words * 8));
+      HIP_OK(hipMemsetAsync(probe_image, 0, words * 8, D[0].stream));
       for (int rep = 0; rep < 2; ++rep) {  // the first launch pays one-off costs
-        ABI_OK(mcgpu_launch_projection(ctx, first, mode, (int)seed, 0, probe_units, (int)hpt, D[0].image[0], D[0].stream));
+        ABI_OK(mcgpu_launch_projection(ctx, first, mode, (int)seed, 0, probe_units, (int)hpt, probe_image, D[0].stream));
         ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
       }
-      HIP_OK(hipMemsetAsync(D[0].image[0], 0, words * 8, D[0].stream));
       ABI_OK(mcgpu_dose_clear(ctx));
       const double rate = (double)probe / (ms > 0.f ? ms * 1e-3 : 1e-3) * n_ctx;
       H = (unsigned long long)(rate * (double)hist_in);
@@ -205,13 +203,15 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         !getenv("MCGPU_SWAP_BATCH") && !getenv("MCGPU_NO_AUTOTUNE")) {
       static const int presets[3][5] = {{32, 8, 36, 12, 40}, {32, 4, 40, 8, 32}, {24, 8, 36, 12, 24}};
       const unsigned long long probe = 6000000ULL;
+      if (!probe_image) HIP_OK(hipMalloc(&probe_image, words * 8));
+      HIP_OK(hipMemsetAsync(probe_image, 0, words * 8, D[0].stream));
       int best = 0;
       float best_ms = 1e30f;
       for (int c = 0; c < 3; ++c) {
         ABI_OK(mcgpu_set_fast_schedule(ctx, presets[c][0], presets[c][1], presets[c][2], presets[c][3], presets[c][4]));
         float ms = 0.f, fastest = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {  // the first launch of a preset pays the parameter upload
-          ABI_OK(mcgpu_launch_projection(ctx, first + (count > 0 ? sim[0] : 0), mode, (int)seed, 0, probe, (int)hpt, D[0].image[0], D[0].stream));
+          ABI_OK(mcgpu_launch_projection(ctx, first + (count > 0 ? sim[0] : 0), mode, (int)seed, 0, probe, (int)hpt, probe_image, D[0].stream));
           ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
           if (rep > 0 && ms < fastest) fastest = ms;
         }
@@ -220,7 +220,6 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       for (int g = 0; g < n_ctx; ++g)
         ABI_OK(mcgpu_set_fast_schedule(D[g].ctx, presets[best][0], presets[best][1], presets[best][2], presets[best][3], presets[best][4]));
       HIP_OK(hipSetDevice(D[0].dev));
-      HIP_OK(hipMemsetAsync(D[0].image[0], 0, words * 8, D[0].stream));
       ABI_OK(mcgpu_dose_clear(ctx));
       if (opt->progress) {
         printf("       FAST batching preset %d of 3 (thresholds %d/%d/%d, %d, %d)\n", best + 1, presets[best][0], presets[best][1], presets[best][2],
@@ -229,14 +228,26 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       }
     }
     for (int g = 0; g < n_ctx; ++g) { D[g].lo = units * g / n_ctx; D[g].hi = units * (g + 1) / n_ctx; }
+    if (probe_image) {
+      HIP_OK(hipStreamSynchronize(D[0].stream));
+      HIP_OK(hipFree(probe_image));
+      probe_image = nullptr;
+    }
+    for (int g = 0; g < n_ctx; ++g) {  // every device that can own a projection finalizes it
+      if (g > 0 && !(policy & MCGPU_EXCHANGE_ROTATE)) break;
+      HIP_OK(hipSetDevice(D[g].dev));
+      for (int b = 0; b < 2; ++b) {
+        HIP_OK(hipMalloc(&D[g].planes_dev[b], 3 * plane * 4));
+        // the writer thread reads non-coherent pinned memory after waiting on this event: that needs a SYSTEM-scope release,
+        // which a default event does not promise (device scope only)
+        HIP_OK(hipEventCreateWithFlags(&D[g].done[b], hipEventDisableTiming | hipEventReleaseToSystem));
+      }
+    }
+    HIP_OK(hipSetDevice(D[0].dev));
     for (int b = 0; b < 2; ++b) {
-      HIP_OK(hipMalloc(&planes_dev[b], 3 * plane * 4));
-      // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte (ordering: see the event below)
+      // non-coherent (CPU-cacheable) pinned memory: the writer thread reads every byte (ordering: see the event above)
       HIP_OK(hipHostMalloc((void**)&planes_host[b], 3 * plane * 4, pinned_flags));
       if (opt->write_ascii && ascii_on_host) HIP_OK(hipHostMalloc((void**)&image_host[b], words * 8, pinned_flags));
-      // the writer thread reads non-coherent pinned memory after waiting on this event: that needs a SYSTEM-scope release,
-      // which a default event does not promise (device scope only)
-      HIP_OK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming | hipEventReleaseToSystem));
     }
     const bool shared = opt->shared_stacks != nullptr;  // 4-D: the caller owns stacks that several scans fill by slice index
     if (shared && !opt->slice_of_projection) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: shared_stacks needs slice_of_projection"};
@@ -253,15 +264,17 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
           for (;;) {
             int p;
             double secs;
+            mcgpu_ctx* fctx;
             {
               std::unique_lock<std::mutex> lk(sh.mu);
               sh.cv.wait(lk, [&] { return sh.ascii_busy[b] || sh.ascii_quit || sh.abort; });
               if (!sh.ascii_busy[b]) return;
               p = sh.ascii_p[b];
               secs = sh.ascii_seconds[b];
+              fctx = sh.ascii_ctx[b];
             }
             const double tw0 = now_s();
-            const int wrc = mcgpu_write_formatted_projection(ctx, p, b, total, secs, nullptr);
+            const int wrc = mcgpu_write_formatted_projection(fctx, p, b, total, secs, nullptr);
             std::lock_guard<std::mutex> lk(sh.mu);
             sh.writer_s += now_s() - tw0;
             if (wrc != 0) { sh.error = mcgpu_last_error(); sh.abort = true; }
@@ -278,8 +291,8 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
           sh.cv.wait(lk, [&] { return sh.queued > i || sh.abort; });
           if (sh.abort) return;
         }
-        const int b = i & 1, p = first + sim[i];
-        if (hipSetDevice(D[0].dev) != hipSuccess || hipEventSynchronize(done[b]) != hipSuccess) {
+        const int b = i & 1, p = first + sim[i], o = mcgpu_exchange_owner(D[0].x, i);
+        if (hipSetDevice(D[o].dev) != hipSuccess || hipEventSynchronize(D[o].done[b]) != hipSuccess) {
           std::lock_guard<std::mutex> lk(sh.mu);
           sh.error = "!!HIP ERROR!! waiting for projection results";
           sh.abort = true;
@@ -311,6 +324,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         if (wrc == 0 && ascii_async) {  // the slot is free: the projection loop waited for that before it formatted into it
           const int a = i % n_ascii;
           sh.ascii_p[a] = p;
+          sh.ascii_ctx[a] = D[o].ctx;
           sh.ascii_seconds[a] = (double)kms[i] * 1e-3;
           sh.ascii_busy[a] = true;
         }
@@ -329,9 +343,9 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     if (mode == MCGPU_MODE_COMPAT)  // the seed moves on per SIMULATED projection (MC-GPU_v1.3.cu:869)
       for (int p = 0; p < first; ++p)
         if (!outside_roi(p)) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
-    // reduce + finalize of projection j on device 0's stream, then hand it to the writer
+    // sum + finalize of projection j on its owner's stream, then hand it to the writer
     auto enqueue_reduce = [&](int j) {
-      const int b = j & 1, t = single ? 0 : b;
+      const int b = j & 1, o = mcgpu_exchange_owner(D[0].x, j);
       {  // pinned buffer b is free once projection j-2 has been written.  Formatter slot j % n_ascii was last used by
          // projection j - n_ascii: that one must have been HANDED to its worker (the writer sets ascii_busy when it has
          // written the projection's stacks, together with `written`) and the worker must be done.  With one slot the
@@ -342,21 +356,20 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         sh.cv.wait(lk, [&] { return (sh.written >= handed && !sh.ascii_busy[j % n_ascii]) || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
-      HIP_OK(hipSetDevice(D[0].dev));
-      for (int g = 1; g < n_ctx; ++g) {
-        HIP_OK(hipStreamWaitEvent(s0, D[g].pushed[b], 0));
-        HIP_OK(mcgpu::launch_accumulate((unsigned long long*)D[0].image[t], (const unsigned long long*)D[g].landing[b], words, s0));
-      }
-      if (!single) HIP_OK(hipEventRecord(consumed[b], s0));
-      // the reference's ASCII file: its 63 MB of text are formatted on the device (ascii_device.hip) before the tally is
-      // cleared; the writer thread downloads and writes them while the next projection is tracked
+      HIP_OK(hipSetDevice(D[o].dev));
+      hipStream_t const so = D[o].stream;
+      void* tally = nullptr;
+      ABI_OK(mcgpu_exchange_collect(D[o].x, j, so, &tally));  // the landed tallies of the other devices, added in one pass
+      if (!tally) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: the owner of a projection got no tally"};
+      // the reference's ASCII file: its 63 MB of text are formatted on the device (ascii_device.hip) while the tally is
+      // there; the writer thread downloads and writes them while the next projection is tracked
       if (opt->write_ascii) {
-        if (ascii_on_host) HIP_OK(hipMemcpyAsync(image_host[b], D[0].image[t], words * 8, hipMemcpyDeviceToHost, s0));
-        else ABI_OK(mcgpu_format_projection(ctx, D[0].image[t], total, j % n_ascii, s0));
+        if (ascii_on_host) HIP_OK(hipMemcpyAsync(image_host[b], tally, words * 8, hipMemcpyDeviceToHost, so));
+        else ABI_OK(mcgpu_format_projection(D[o].ctx, tally, total, j % n_ascii, so));
       }
-      ABI_OK(mcgpu_finalize_projection(ctx, D[0].image[t], total, cx, planes_dev[b], 1, s0));
-      HIP_OK(hipMemcpyAsync(planes_host[b], planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, s0));
-      HIP_OK(hipEventRecord(done[b], s0));
+      ABI_OK(mcgpu_finalize_projection(D[o].ctx, tally, total, cx, D[o].planes_dev[b], 0, so));  // begin() zeroes the buffer for its next user
+      HIP_OK(hipMemcpyAsync(planes_host[b], D[o].planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, so));
+      HIP_OK(hipEventRecord(D[o].done[b], so));
     };
     auto publish = [&](int j) {  // kms[j] is final: the writer may take projection j
       std::lock_guard<std::mutex> lk(sh.mu);
@@ -370,25 +383,22 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
                (angle0 + (first + k) * d_angle) * kRad2Deg);
     };
     for (int i = 0; i < count; ++i) {
-      const int b = i & 1, p = first + sim[i];
+      const int p = first + sim[i];
       print_skipped(i ? sim[i - 1] + 1 : 0, sim[i]);
       if (nproj_all != 1 && opt->progress) {
         printf("\n\n\n   << Simulating Projection %d of %d >>\n\n\n", p + 1, (int)nproj_all);  // cbctmc/mc/simulation.py:200-219 parses this
         fflush(stdout);
       }
-      // every device tracks its shard into a zeroed tally buffer; peers then push theirs to device 0 and clear it
+      // every device tracks its shard into a zeroed tally buffer; the devices that do not own the projection then push theirs
+      // to the owner (copy engine, beside the next projection's kernel)
       for (int g = 0; g < n_ctx; ++g) {
         HIP_OK(hipSetDevice(D[g].dev));
-        void* const tally = D[g].image[(g == 0 && !single) ? b : 0];
+        void* tally = nullptr;
+        ABI_OK(mcgpu_exchange_begin(D[g].x, i, D[g].stream, &tally));
         ABI_OK(mcgpu_launch_projection(D[g].ctx, p, mode, cur_seed, D[g].lo, D[g].hi - D[g].lo, hpt_eff, tally, D[g].stream));
-        if (g > 0) {
-          if (i >= 2) HIP_OK(hipStreamWaitEvent(D[g].stream, consumed[b], 0));  // landing[b] still holds projection i-2 until then
-          HIP_OK(hipMemcpyPeerAsync(D[g].landing[b], D[0].dev, tally, D[g].dev, words * 8, D[g].stream));
-          HIP_OK(hipEventRecord(D[g].pushed[b], D[g].stream));
-          HIP_OK(hipMemsetAsync(tally, 0, words * 8, D[g].stream));
-        }
+        ABI_OK(mcgpu_exchange_submit(D[g].x, i, D[g].stream));
       }
-      // device 0, behind its own kernel i: the previous projection (one device: this one)
+      // the owner of the previous projection, behind its own kernel i (one device: this projection)
       if (single) enqueue_reduce(i);
       else if (i >= 1) { enqueue_reduce(i - 1); publish(i - 1); }
       // kernel time of this projection = the slowest device's launch; waiting for it also paces the host
@@ -474,23 +484,25 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   }
   if (D[0].dev >= 0) {
     (void)hipSetDevice(D[0].dev);
+    if (probe_image) (void)hipFree(probe_image);
     for (int b = 0; b < 2; ++b) {
-      if (planes_dev[b]) (void)hipFree(planes_dev[b]);
       if (planes_host[b]) (void)hipHostFree(planes_host[b]);
       if (image_host[b]) (void)hipHostFree(image_host[b]);
-      if (done[b]) (void)hipEventDestroy(done[b]);
-      if (consumed[b]) (void)hipEventDestroy(consumed[b]);
-      for (auto& d : D)
-        if (d.landing[b]) (void)hipFree(d.landing[b]);
     }
   }
   for (auto& d : D) {
     if (d.dev < 0) continue;
     (void)hipSetDevice(d.dev);
     for (int b = 0; b < 2; ++b) {
-      if (d.image[b]) (void)hipFree(d.image[b]);
-      if (d.pushed[b]) (void)hipEventDestroy(d.pushed[b]);
+      if (d.planes_dev[b]) (void)hipFree(d.planes_dev[b]);
+      if (d.done[b]) (void)hipEventDestroy(d.done[b]);
     }
+  }
+  for (auto& d : D)  // after every device has drained: an exchange end frees memory its peers push into
+    if (d.x) mcgpu_exchange_destroy(d.x);
+  for (auto& d : D) {
+    if (d.dev < 0) continue;
+    (void)hipSetDevice(d.dev);
     if (d.stream) (void)hipStreamDestroy(d.stream);
   }
   return rc;

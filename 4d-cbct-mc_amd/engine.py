@@ -30,6 +30,9 @@ ABI_SYMBOLS = (
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
     "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
+    "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
+    "mcgpu_exchange_connect_local", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
+    "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
 )
 
 
@@ -115,6 +118,22 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_write_voxel_binary.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
     lib.mcgpu_reload_env_knobs.argtypes = [vp]
+    lib.mcgpu_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.mcgpu_exchange_shared_bytes.argtypes = [ci]
+    lib.mcgpu_exchange_shared_bytes.restype = C.c_size_t
+    lib.mcgpu_exchange_card_bytes.argtypes = [ci]
+    lib.mcgpu_exchange_card_bytes.restype = C.c_size_t
+    lib.mcgpu_exchange_create.argtypes = [ci, ci, ci, C.c_size_t, ci, vp, C.POINTER(vp)]
+    lib.mcgpu_exchange_card.argtypes = [vp, vp, C.c_size_t]
+    lib.mcgpu_exchange_connect.argtypes = [vp, ci, vp, C.c_size_t]
+    lib.mcgpu_exchange_connect_local.argtypes = [vp, vp]
+    lib.mcgpu_exchange_owner.argtypes = [vp, C.c_longlong]
+    lib.mcgpu_exchange_begin.argtypes = [vp, C.c_longlong, vp, C.POINTER(vp)]
+    lib.mcgpu_exchange_submit.argtypes = [vp, C.c_longlong, vp]
+    lib.mcgpu_exchange_collect.argtypes = [vp, C.c_longlong, vp, C.POINTER(vp)]
+    lib.mcgpu_exchange_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.mcgpu_exchange_destroy.argtypes = [vp]
+    lib.mcgpu_exchange_destroy.restype = None
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     if path is None:
         _lib = lib
@@ -206,6 +225,91 @@ def normalize_stack(total_stack, air_stack, out_stack, sigma=(10.0, 10.0), spaci
                                                 float(spacing[0]), float(spacing[1])))
 
 
+EXCHANGE_ROOT0, EXCHANGE_ROTATE, EXCHANGE_LOCAL = 0, 1, 2
+
+
+class Exchange:
+    """One rank's end of the tally exchange between the GPUs of one node (mcgpu_exchange_*, include/mcgpu_amd.h): per step
+    `begin` -> launch into the returned buffer -> `submit` -> `collect(previous step)`.
+
+    `shared`: a writable buffer of `Exchange.shared_bytes(world)` zeroed bytes seen by every rank -- an `mmap` of one
+    /dev/shm file between processes (`Exchange.open_shared`), a bytearray between contexts of one process."""
+
+    def __init__(self, device: int, rank: int, world: int, words: int, shared, policy: int = EXCHANGE_ROOT0):
+        self.lib = load_library()
+        self._shared = shared  # keeps the mapping alive
+        self._buf = (C.c_char * len(shared)).from_buffer(shared)
+        if len(shared) < self.shared_bytes(world):
+            raise ValueError("shared region too small")
+        h = C.c_void_p()
+        _check(self.lib.mcgpu_exchange_create(int(device), int(rank), int(world), int(words), int(policy), C.addressof(self._buf), C.byref(h)))
+        self.h, self.rank, self.world, self.words, self.policy = h, rank, world, words, policy
+
+    @staticmethod
+    def shared_bytes(world: int) -> int:
+        return int(load_library().mcgpu_exchange_shared_bytes(int(world)))
+
+    @staticmethod
+    def open_shared(path, world: int, create: bool):
+        """Map the host region of an exchange between processes: rank 0 creates (and zeroes) the file BEFORE the others open it."""
+        import mmap
+        n = Exchange.shared_bytes(world)
+        if create:
+            with open(path, "wb") as f:
+                f.write(b"\0" * n)
+        f = open(path, "r+b")
+        try:
+            return mmap.mmap(f.fileno(), n)
+        finally:
+            f.close()
+
+    def card(self) -> bytes:
+        n = int(self.lib.mcgpu_exchange_card_bytes(self.world))
+        buf = C.create_string_buffer(n)
+        _check(self.lib.mcgpu_exchange_card(self.h, buf, n))
+        return buf.raw
+
+    def connect(self, peer: int, card: bytes):
+        _check(self.lib.mcgpu_exchange_connect(self.h, int(peer), card, len(card)))
+
+    def connect_local(self, other: "Exchange"):
+        _check(self.lib.mcgpu_exchange_connect_local(self.h, other.h))
+
+    def owner(self, step: int) -> int:
+        return int(self.lib.mcgpu_exchange_owner(self.h, int(step)))
+
+    def begin(self, step: int, stream: int = 0) -> int:
+        p = C.c_void_p()
+        _check(self.lib.mcgpu_exchange_begin(self.h, int(step), C.c_void_p(stream), C.byref(p)))
+        return p.value
+
+    def submit(self, step: int, stream: int = 0):
+        _check(self.lib.mcgpu_exchange_submit(self.h, int(step), C.c_void_p(stream)))
+
+    def collect(self, step: int, stream: int = 0) -> Optional[int]:
+        """Device pointer of the complete tally of `step` on its owner (valid until begin(step + 2)), None elsewhere."""
+        p = C.c_void_p()
+        _check(self.lib.mcgpu_exchange_collect(self.h, int(step), C.c_void_p(stream), C.byref(p)))
+        return p.value
+
+    def stats(self) -> dict:
+        out = (C.c_double * 6)()
+        _check(self.lib.mcgpu_exchange_stats(self.h, out))
+        return {"last_push_ms": out[0], "last_add_ms": out[1], "pushes": int(out[2]), "collects": int(out[3]), "host_wait_s": out[4], "bytes_per_push": int(out[5])}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mcgpu_exchange_destroy(self.h)
+            self.h = None
+            del self._buf
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One loaded simulation (input file + tables), optionally resident on one GPU."""
 
@@ -289,6 +393,13 @@ class Context:
 
     def clear(self, image_dev_ptr: int, stream: int = 0):
         _check(self.lib.mcgpu_clear_image(self.h, C.c_void_p(image_dev_ptr), C.c_void_p(stream)))
+
+    def download_image(self, image_dev_ptr: int, stream: int = 0) -> np.ndarray:
+        """uint64[4, Nz, Nx] copy of a device tally (waits for `stream`)."""
+        img = np.zeros(self.image_words, dtype=np.uint64)
+        _check(self.lib.mcgpu_copy_to_host(self.h, C.c_void_p(image_dev_ptr), img.ctypes.data, img.nbytes, C.c_void_p(stream)))
+        nz, nx = self.detector_shape
+        return img.reshape(4, nz, nx)
 
     def reload_env_knobs(self):
         """Read the MCGPU_* tuning knobs of the environment again (they are otherwise read once, at creation)."""

@@ -88,5 +88,18 @@ def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "sca
     return send.numel() * send.element_size() + part_w.numel() * part_w.element_size()
 
 
+def connect_exchange(x, dist) -> None:
+    """Swap the address cards of a tally exchange (engine.Exchange: IPC memory and event handles of every rank's landing
+    buffer) between the ranks of the initialised process group `dist` (torch.distributed, any backend) and connect this
+    rank's end to every peer.  Collective: every rank calls it once."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cards = [None] * world
+    dist.all_gather_object(cards, x.card())
+    for peer in range(world):
+        if peer != rank:
+            x.connect(peer, cards[peer])
+    dist.barrier()  # nobody starts pushing before everybody has mapped everybody
+
+
 _BUFFERS: dict = {}
 _MAX_BUFFER_SETS = 4

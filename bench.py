@@ -7,12 +7,26 @@ PENELOPE material tables.  `--workload cirs` / `thorax` run the same measurement
 geometry) and on the patient-like 512x512x256 thorax (config 4 shape); they are not the headline.
 
 A "step" is one projection: the photon-history kernel over one batch of histories (FAST personality), plus -- for N > 1 -- the
-RCCL sum-reduce of the detector tally to rank 0.  Inputs (volume, tables) are resident in HBM before the timed region.
-Weak scaling: every rank simulates `--histories` histories of each projection with its own disjoint history-id range.
+sum of the per-rank detector tallies (the reference's MPI_Reduce, MC-GPU_v1.3.cu:1019) through the engine's tally exchange
+(4d-cbct-mc_amd/csrc/exchange.cpp: copy-engine pushes into the owner's landing buffer beside the next projection's kernel,
+one fused add on the owner; `BENCH_EXCHANGE=rccl` runs the plain RCCL reduction instead).  Inputs (volume, tables) are
+resident in HBM before the timed region.  Weak scaling: every rank simulates `--histories` histories of each projection
+with its own disjoint history-id range.
 
-Prints ONE JSON line on rank 0 (driver contract) carrying `roofline` and `cpu_baseline`, plus (1 GPU) a driver-timed leg of the
-COMPAT personality (`compat`: the reference's RANECU streams and arithmetic, bit-identical to the oracle), a correctness
-figure tied to the oracle (`check`) and the pipelined-scan figure (`end_to_end`).
+Ranks: one process per GPU.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) the
+ranks exist already (RANK / LOCAL_RANK / WORLD_SIZE in the environment).  Without one, `python bench.py --gpus N` starts the
+N rank processes ITSELF (before this process has touched the GPU or imported anything that could), waits for them and relays
+rank 0's line -- like the reference's `mpirun -n N` inside `MCSimulation.run_simulation` (cbctmc/mc/simulation.py:187-198,
+MC-GPU_v1.3.cu:389-391).  A rank count that cannot be honoured (fewer GPUs than ranks) exits non-zero; `BENCH_SHARE_GPU=1`
+lets the ranks share the GPUs there are (development: two ranks on a one-GPU box exercise the whole N > 1 path).
+
+Prints ONE JSON line on rank 0 (driver contract) carrying `roofline` and `cpu_baseline`.  At N = 1 the line also carries
+driver-timed legs measured after the timed region: `compat` (the bit-exact personality), `check` (FAST against the oracle;
+a failed check exits non-zero), `end_to_end` (the whole 894-projection scan with the MetaImage stacks on disk),
+`end_to_end_ascii` (the drop-in default: the reference's 63 MB text file per projection) and `workloads` (the same kernel
+measurement on the CIRS phantom and the patient-like thorax, configs 3-5).  At N > 1: `reduce` (bytes, copy-engine time,
+the exposed add) and `check.sharded_equals_single` (the summed sharded tally against one rank simulating the same history
+ids alone, bit for bit).
 """
 from __future__ import annotations
 
@@ -20,6 +34,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -190,19 +206,142 @@ def oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu):
             "passed": bool(all((not np.isfinite(v)) or abs(v) < 4.0 for v in zs) and (zz.size == 0 or np.mean(np.abs(zz) > 3.0) < 0.01))}
 
 
-def end_to_end_scan(ctx, H, workdir, n=224):
-    """The pipelined scan driver (track -> finalize -> pinned copy -> writer thread) with the three MetaImage stacks
-    written to disk: per-projection wall time including output, reported beside the kernel-only figure."""
-    out = workdir / "scan_out"
+def end_to_end_scan(ctx, H, workdir, n=894, ascii_files=False):
+    """The pipelined scan driver (track -> finalize -> pinned copy -> writer thread) over `n` projections with its output on
+    disk: the three MetaImage stacks, or (`ascii_files`) the reference's ASCII file per projection -- 63 MB of text each,
+    formatted on the device (the unchanged-cbctmc drop-in default).  Per-projection wall time including output."""
+    out = workdir / ("scan_ascii" if ascii_files else "scan_out")
     out.mkdir(exist_ok=True)
     crop = 1024 if ctx.detector_shape[1] == 1848 else 0
-    rep = ctx.run_scan(mode="fast", first_projection=100, num_projections=n, histories=H, crop_nx=crop, write_stacks=True, output_folder=out,
-                       pixel_spacing=(0.776, 0.776))
+    first = min(100, max(ctx.num_projections - n, 0))
+    rep = ctx.run_scan(mode="fast", first_projection=first, num_projections=n, histories=H, crop_nx=crop, write_stacks=not ascii_files,
+                       write_ascii=ascii_files, output_folder=out, pixel_spacing=(0.776, 0.776))
     for f in out.glob("projections_*.mha"):
         f.unlink()
-    return {"projections": n, "seconds_total": rep["seconds_total"], "histories_per_s_with_stacks": n * H / rep["seconds_total"],
-            "ms_per_projection_with_stacks": rep["seconds_total"] / n * 1e3, "ms_per_projection_kernels": rep["seconds_kernels"] / n * 1e3,
-            "writer_ms_per_projection": rep["seconds_writer"] / n * 1e3, "drain_after_last_kernel_ms": rep["seconds_after_last_kernel"] * 1e3}
+    res = {"projections": n, "seconds_total": rep["seconds_total"], "ms_per_projection_kernels": rep["seconds_kernels"] / n * 1e3,
+           "writer_ms_per_projection": rep["seconds_writer"] / n * 1e3, "drain_after_last_kernel_ms": rep["seconds_after_last_kernel"] * 1e3}
+    if ascii_files:
+        files = [Path(ctx.projection_file_name(p)) for p in range(first, first + n)]
+        res["file_bytes_mean"] = float(np.mean([f.stat().st_size for f in files if f.exists()]))
+        res["files_written"] = int(sum(f.exists() for f in files))
+        for f in files:
+            f.unlink(missing_ok=True)
+        res["histories_per_s_with_ascii_files"] = n * H / rep["seconds_total"]
+        res["ms_per_projection_with_ascii_files"] = rep["seconds_total"] / n * 1e3
+    else:
+        res["histories_per_s_with_stacks"] = n * H / rep["seconds_total"]
+        res["ms_per_projection_with_stacks"] = rep["seconds_total"] / n * 1e3
+    return res
+
+
+def timed_launches(ctx, torch, H, launches=8, warm=2):
+    """Mean kernel time [ms] of `launches` FAST launches of H histories (HIP events on the launch stream), after `warm` untimed."""
+    nz, nx = ctx.detector_shape
+    image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    seed, nproj, ms = ctx.geti("seed"), ctx.num_projections, []
+    for i in range(warm + launches):
+        ctx.clear(image.data_ptr(), stream)
+        ctx.launch((i * 149) % nproj, image.data_ptr(), H, mode="fast", seed=seed, stream=stream)
+        t = ctx.last_kernel_ms()
+        if i >= warm:
+            ms.append(t)
+    return float(np.mean(ms)), float(np.min(ms)), int(image.sum().item())
+
+
+def roofline_block(workload, H, k_ms):
+    """`roofline` object of one workload: algorithmic bytes of the reference layout over the measured kernel time, plus the
+    PMC-counter traffic of this kernel build when a stamped summary of it is committed."""
+    label, algo_bytes, algo_src = WORKLOADS[workload]
+    achieved = algo_bytes * H / (k_ms * 1e-3) / 1e9
+    pmc, pmc_src = pmc_summary(workload) if H == int(1e8) else (None, "summary is per 1e8-history launch")
+    traffic = hbm_counter_frac = valu = l2_hit = None
+    if pmc:
+        # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled
+        # (MI355X_MICROARCH.md, HBM section)
+        traffic = (2.0 * pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+        hbm_counter_frac = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        insts = pmc["SQ_INSTS_VALU"]["mean_per_dispatch"]
+        if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+            l2_hit = pmc["TCC_HIT_sum"]["mean_per_dispatch"] / max(pmc["TCC_HIT_sum"]["mean_per_dispatch"] + pmc["TCC_MISS_sum"]["mean_per_dispatch"], 1.0)
+        # ceiling: a dense dependent-FMA kernel, 8 waves/SIMD, 16-32 active lanes, on the same chip (tools/micro/exec_skip.hip:
+        # 5.24e9 wave-instructions on 1024 SIMDs in 5.1 ms)
+        peak = 5.24e9 / 1024.0 / 5.1e6
+        valu = {"valu_wave_instructions_per_launch": insts, "valu_wave_instructions_per_history": insts / H,
+                "achieved_per_ns_per_simd": insts / 1024.0 / (k_ms * 1e6),
+                "measured_peak_per_ns_per_simd": peak, "frac": insts / 1024.0 / (k_ms * 1e6) / peak,
+                "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"]["mean_per_dispatch"] / pmc["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / 64.0}
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "hbm_counter_frac": hbm_counter_frac, "traffic_source": pmc_src,
+            "fabric_bytes_per_history": None if traffic is None else traffic / H, "l2_hit_rate": l2_hit,
+            "kernel": "track_pool_kernel<u8> (fast)", "kernel_ms_avg": k_ms, "kernel_source_sha16": kernel_source_hash(),
+            "algorithmic_bytes_per_history": algo_bytes, "algorithmic_bytes_source": algo_src,
+            "algorithmic_bytes_per_launch": algo_bytes * H}
+    return roof, valu
+
+
+def other_workloads(eng, torch, H, projections, device):
+    """Configs 3-5 under the driver's clock: the same kernel measurement (8 launches of H histories) on the bundled CIRS
+    phantom and on the patient-like thorax."""
+    out = {}
+    for wl in ("cirs", "thorax"):
+        t0 = time.perf_counter()
+        wd = Path(os.path.join(tempfile.gettempdir(), f"mcgpu_bench_{wl}_512_{projections}"))
+        inp = wd / "input.in"
+        if not (inp.exists() and (wd / "geometry.voxbin").exists()):
+            wd.mkdir(parents=True, exist_ok=True)
+            build_workload(wd, wl, H, projections, eng)
+        t1 = time.perf_counter()
+        with eng.create(inp, device=device) as c2:
+            k_ms, k_min, detected = timed_launches(c2, torch, H)
+            roof, valu = roofline_block(wl, H, k_ms)
+            out[wl] = {"value": H / (k_ms * 1e-3), "unit": "histories/s", "kernel_ms_avg": k_ms, "kernel_ms_min": k_min, "launches": 8,
+                       "config": WORKLOADS[wl][0], "roofline": {k: roof[k] for k in ("frac", "achieved", "traffic", "hbm_counter_frac", "fabric_bytes_per_history",
+                                                                                     "l2_hit_rate", "traffic_source", "algorithmic_bytes_per_history")},
+                       "valu_issue": valu, "volume_bytes": c2.geti("volume_bytes_device"), "materials_used": c2.geti("num_materials_used"),
+                       "detected_energy_units_last_projection": detected,
+                       "prepare_inputs_s": t1 - t0, "load_measure_s": time.perf_counter() - t1}
+    return out
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters: this process has not touched
+    the GPU and never does), one per GPU, wait, relay rank 0's JSON line.  Any rank failing fails the run."""
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": env0.get("MASTER_PORT", str(free_port())),
+                 "BENCH_SPAWNED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": env0.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    line = procs[0].stdout.read()  # rank 0 prints the one line at its very end
+    rc = 0
+    deadline = time.time() + 600.0
+    for r, p in enumerate(procs):
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the process started here
+            code = -9
+        if code != 0:
+            print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+            rc = rc or (code if code > 0 else 1)
+    if rc == 0 and not line.strip():
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -215,10 +354,19 @@ def main():
     ap.add_argument("--voxels", type=int, default=512, help="catphan workload: cube edge")
     ap.add_argument("--projections", type=int, default=894)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-end-to-end", action="store_true", help="skip the pipelined-scan measurement after the timed region")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the pipelined-scan measurements after the timed region")
     ap.add_argument("--no-compat", action="store_true", help="skip the COMPAT-personality leg")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the CIRS / thorax legs (configs 3-5)")
+    ap.add_argument("--scan-projections", type=int, default=894, help="projections of the end_to_end leg")
+    ap.add_argument("--ascii-projections", type=int, default=64, help="projections of the end_to_end_ascii leg (63 MB of text each)")
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
+    # No launcher gave this process a rank: it becomes the launcher (nothing GPU-related has been imported yet).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner from C stdio on
     # its first collective), so everything else is sent to stderr and the line goes to the original descriptor at the end.
@@ -230,17 +378,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        # the rank count is a fact of the launcher; a line that claims another n_gpus would be mislabelled
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to run a mislabelled measurement")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if world > n_dev and not share:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs, this node shows {n_dev} (BENCH_SHARE_GPU=1 lets ranks share a GPU: development only)")
+    device = local_rank % n_dev if share else local_rank
+    torch.cuda.set_device(device)
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the latter: exercise the collective path on one GPU
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share and world > n_dev:  # RCCL refuses two ranks on one device: the control plane falls back to gloo
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    backend = dist.get_backend() if dist else None
+
+    def barrier():
+        if dist:
+            dist.barrier()
 
     import cases
     eng = cases.pkg.engine
@@ -255,105 +419,161 @@ def main():
     if rank == 0 and not (inp.exists() and (workdir / "geometry.vox").exists() and (workdir / "geometry.voxbin").exists()):
         workdir.mkdir(parents=True, exist_ok=True)
         build_workload(workdir, args.workload, H, args.projections, eng, args.voxels)
-    if dist:
-        dist.barrier()
+    barrier()
     t_prep = time.perf_counter() - t_prep0
     t_load0 = time.perf_counter()
-    ctx = eng.create(inp, device=local_rank)
+    ctx = eng.create(inp, device=device)
     t_load = time.perf_counter() - t_load0
 
     nz, nx = ctx.detector_shape
-    # N > 1: every rank tracks its history shard of G consecutive projections into G tally buffers, then ONE sum-reduction
-    # brings the G tallies to rank 0 (the reference's per-projection MPI_Reduce, MC-GPU_v1.3.cu:1019, batched: fewer, larger
-    # messages; sharding.reduce_image: slices straight to their owners over the point-to-point xGMI links, summed there,
-    # gathered on rank 0).  The reduce is ordered between two tracking kernels on purpose: a kernel that is
-    # still running while the persistent tracking grid is dispatched fragments the CUs' register files for the whole
-    # launch and costs up to 30 % (tools/placement_probe.py), so nothing overlaps a tracking launch.
-    # Payload: 32-bit words whenever the summed tallies provably fit (sharding.reduce_image), else 64-bit.
-    G = max(1, int(os.environ.get("BENCH_REDUCE_GROUP", "8"))) if dist else 1
-    images = torch.zeros((G, 4, nz, nx), dtype=torch.int64, device="cuda")
-    filled = [0]
     stream = torch.cuda.current_stream().cuda_stream
     nproj = ctx.num_projections
     seed = ctx.geti("seed")
     kernel_ms = []
-    narrow = dist is not None and os.environ.get("BENCH_REDUCE_U32", "1") == "1"
-    reduce_algo = os.environ.get("BENCH_REDUCE_ALGO", "scatter")  # sharding.reduce_image: slices to their owners, sum, gather
+    # ---- N > 1: the sum of the per-rank tallies (the reference's MPI_Reduce, MC-GPU_v1.3.cu:1019)
+    #   "copy" (default): the engine's tally exchange -- every projection has an owner rank, the others push their tally into
+    #     its landing buffer with a copy engine while the next projection is tracked, the owner adds them behind its next
+    #     kernel (exchange.cpp; the path the drop-in executable runs between its devices)
+    #   "rccl": sharding.reduce_image, one collective per G projections between two tracking kernels (exposed by design)
+    exchange_kind = os.environ.get("BENCH_EXCHANGE", "copy") if dist else None
+    if dist and backend == "gloo" and exchange_kind == "rccl":
+        raise SystemExit("bench.py: BENCH_EXCHANGE=rccl needs one GPU per rank")
+    x = shared_map = None
+    policy = eng.EXCHANGE_ROTATE if os.environ.get("MCGPU_EXCHANGE_POLICY", "1") != "0" else eng.EXCHANGE_ROOT0
+    if exchange_kind == "copy":
+        shm = Path("/dev/shm") / f"mcgpu_exchange_{os.environ['MASTER_PORT']}"
+        if rank == 0:
+            shared_map = eng.Exchange.open_shared(shm, world, create=True)
+        barrier()
+        if rank != 0:
+            shared_map = eng.Exchange.open_shared(shm, world, create=False)
+        x = eng.Exchange(device, rank, world, ctx.image_words, shared_map, policy)
+        cases.pkg.sharding.connect_exchange(x, dist)
+        if rank == 0:
+            shm.unlink(missing_ok=True)  # every rank holds its mapping
+    G = max(1, int(os.environ.get("BENCH_REDUCE_GROUP", "8"))) if exchange_kind == "rccl" else 1
+    images = None if x else torch.zeros((G, 4, nz, nx), dtype=torch.int64, device="cuda")
+    filled = [0]
+    narrow = exchange_kind == "rccl" and os.environ.get("BENCH_REDUCE_U32", "1") == "1"
+    reduce_algo = os.environ.get("BENCH_REDUCE_ALGO", "scatter")
     reduce_bytes = [0]
+    last_reduced = [None]  # device pointer / tensor of the last complete tally this rank holds
+    n_step = [0]           # exchange step counter (consecutive over warm-up, timed region and the check)
 
     def reduce_group():
-        if dist and filled[0] > 0:
-            # on the current stream: the next tracking launch waits for it (see above)
+        if exchange_kind == "rccl" and filled[0] > 0:
+            # on the current stream: the next tracking launch waits for it
             reduce_bytes[0] += cases.pkg.sharding.reduce_image(images[:filled[0]], dst=0, narrow=narrow, algorithm=reduce_algo)
         filled[0] = 0
 
-    def step(i, timed):
-        p = (i * 149) % nproj  # spread the sampled projections over the arc
-        image = images[filled[0]]
-        ctx.clear(image.data_ptr(), stream)
-        # disjoint history ids per rank: [rank*H, (rank+1)*H)
-        ctx.launch(p, image.data_ptr(), H, mode="fast", seed=seed, first=rank * H, stream=stream)
-        filled[0] += 1
-        last[0] = filled[0] - 1
+    collected = [0]        # exchange steps collected so far (each step is collected exactly once, in order)
+
+    def collect_up_to(k_excl):
+        while x and collected[0] < k_excl:
+            got = x.collect(collected[0], stream)
+            last_reduced[0] = got or last_reduced[0]
+            collected[0] += 1
+
+    def step(i, timed, hist=H, projection=None):
+        p = (i * 149) % nproj if projection is None else projection  # spread the sampled projections over the arc
+        if x:
+            k = n_step[0]
+            tally = x.begin(k, stream)
+            ctx.launch(p, tally, hist, mode="fast", seed=seed, first=rank * hist, stream=stream)  # disjoint history ids per rank
+            x.submit(k, stream)
+            collect_up_to(k)  # step k - 1, behind this kernel: its pushes had the whole kernel to land
+            n_step[0] = k + 1
+        else:
+            image = images[filled[0]]
+            ctx.clear(image.data_ptr(), stream)
+            ctx.launch(p, image.data_ptr(), hist, mode="fast", seed=seed, first=rank * hist, stream=stream)
+            filled[0] += 1
+            last_reduced[0] = image
         if timed:
             kernel_ms.append(ctx.last_kernel_ms())  # waits for this launch only
-        if filled[0] == G:
+        if not x and filled[0] == G:
             reduce_group()
 
-    last = [0]
-    drain = reduce_group
+    def drain():
+        collect_up_to(n_step[0])
+        reduce_group()
 
     for i in range(args.warmup):
         step(i, False)
-    drain()
-    if dist:
+    if exchange_kind == "rccl":
+        drain()
         # the reductions of the timed region (full groups of G projections and the remainder group) run once untimed: RCCL
         # sets up its channels and sharding.reduce_image its staging buffers on the first call with a payload shape
         for size in sorted({G if args.steps >= G else 0, args.steps % G} - {0}):
             cases.pkg.sharding.reduce_image(images[:size], dst=0, narrow=narrow, algorithm=reduce_algo)
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     reduce_bytes[0] = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, True)
     drain()
-    if dist:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    detected = int(images[last[0]].sum().item()) if rank == 0 else 0
 
+    # ---- N > 1: correctness of the sharded sum, and what the exchange cost
+    multi = None
+    if dist:
+        h = int(float(os.environ.get("BENCH_CHECK_HISTORIES", "1e7")))
+        p_chk = 447 % nproj
+        if x:
+            k_chk = n_step[0]
+            step(0, False, hist=h, projection=p_chk)
+            drain()
+            owner = x.owner(k_chk)
+            if rank == owner:
+                sharded = ctx.download_image(last_reduced[0], stream)
+        else:
+            owner = 0
+            step(0, False, hist=h, projection=p_chk)
+            drain()
+            if rank == 0:
+                torch.cuda.synchronize()
+                sharded = images[0].cpu().numpy().view(np.uint64)
+        barrier()
+        verdict = None
+        if rank == owner:  # the others idle: one rank simulates ALL the history ids [0, world * h) of that projection alone
+            alone, _, done = ctx.run_projection(p_chk, world * h, mode="fast", seed=seed, first=0)
+            verdict = {"passed": bool(np.array_equal(alone, sharded)), "projection": p_chk, "histories_per_rank": h, "ranks": world,
+                       "checked_on_rank": rank, "words_differing": int(np.count_nonzero(alone != sharded)),
+                       "detected_energy_units": int(alone.sum())}
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, verdict)
+        stats = [None] * world
+        dist.all_gather_object(stats, (x.stats() if x else None, float(np.mean(kernel_ms))))
+        multi = {"sharded_equals_single": verdicts[owner], "stats": stats}
+
+    detected = 0
+    if last_reduced[0] is not None and (not dist):
+        detected = int(last_reduced[0].sum().item())
+
+    failed = False
     if rank == 0:
         total_hist = float(H) * world * args.steps
         value = total_hist / elapsed
         k_ms = float(np.mean(kernel_ms))
-        achieved = algo_bytes * H / (k_ms * 1e-3) / 1e9
-        pmc, pmc_src = pmc_summary(args.workload) if H == int(1e8) else (None, "summary is per 1e8-history launch")
-        traffic = hbm_counter_frac = valu = None
-        if pmc:
-            # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled
-            # (MI355X_MICROARCH.md, HBM section)
-            traffic = (2.0 * pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
-            hbm_counter_frac = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            insts = pmc["SQ_INSTS_VALU"]["mean_per_dispatch"]
-            # ceiling: a dense dependent-FMA kernel, 8 waves/SIMD, 16-32 active lanes, on the same chip (tools/micro/exec_skip.hip:
-            # 5.24e9 wave-instructions on 1024 SIMDs in 5.1 ms)
-            peak = 5.24e9 / 1024.0 / 5.1e6
-            valu = {"valu_wave_instructions_per_launch": insts, "achieved_per_ns_per_simd": insts / 1024.0 / (k_ms * 1e6),
-                    "measured_peak_per_ns_per_simd": peak, "frac": insts / 1024.0 / (k_ms * 1e6) / peak,
-                    "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"]["mean_per_dispatch"] / pmc["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / 64.0}
+        roof, valu = roofline_block(args.workload, H, k_ms)
         out = {
             "metric": "photon histories/sec (512^3 vol, 894 proj)", "value": value, "unit": "histories/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
                        "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
-                       "parallelism": f"history-sharded x{world}" + (f", one RCCL sum-reduction ({reduce_algo}) of the detector tallies per {G} projections" if dist else ""),
+                       "parallelism": f"history-sharded x{world}" + ("" if not dist else
+                                      (", tally exchange: copy-engine pushes to the projection's owner (" + ("owner = projection mod ranks" if policy == eng.EXCHANGE_ROTATE else "owner = rank 0") + "), one fused add per projection"
+                                       if x else f", one RCCL sum-reduction ({reduce_algo}) of the detector tallies per {G} projections")),
+                       "ranks_started_by": "bench.py itself" if os.environ.get("BENCH_SPAWNED") else ("an external launcher" if dist else "single process"),
+                       "process_group_backend": backend, "ranks_share_gpus": bool(share and world > n_dev),
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
                        "volume_bytes": ctx.geti("volume_bytes_device"), "materials_used": ctx.geti("num_materials_used"),
                        "lds_bytes_per_workgroup": ctx.geti("lds_bytes_fast"), "workgroups_per_cu": ctx.geti("blocks_per_cu"),
@@ -361,22 +581,44 @@ def main():
             # frac: the reference algorithm's bytes per history (what a history NEEDS in the reference layout) over the kernel
             # time, against the HBM peak -- a model figure.  hbm_counter_frac: the bytes that actually crossed the HBM interface
             # (PMC counters of this kernel build) over the same time.
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "hbm_counter_frac": hbm_counter_frac, "traffic_source": pmc_src,
-                         "kernel": "track_pool_kernel<u8> (fast)", "kernel_ms_avg": k_ms, "kernel_source_sha16": kernel_source_hash(),
-                         "algorithmic_bytes_per_history": algo_bytes, "algorithmic_bytes_source": algo_src,
-                         "algorithmic_bytes_per_launch": algo_bytes * H},
+            "roofline": roof,
             "valu_issue": valu,
             "timing": {"prepare_inputs_s": t_prep, "load_and_upload_s": t_load},
             "check": {"detected_energy_units_last_projection": detected},
         }
-        if dist:
-            out["reduce"] = {"bytes_per_rank_in_timed_region": reduce_bytes[0], "narrowed_to_u32_when_it_fits": bool(narrow), "algorithm": reduce_algo}
+        if multi:
+            v = multi["sharded_equals_single"]
+            out["check"]["sharded_equals_single"] = v
+            out["check"]["passed"] = bool(v and v["passed"])
+            failed = failed or not out["check"]["passed"]
+            k_all = [s_[1] for s_ in multi["stats"]]
+            red = {"kind": exchange_kind, "kernel_ms_avg_per_rank": k_all, "step_minus_slowest_kernel_ms": elapsed / args.steps * 1e3 - max(k_all)}
+            if x:
+                st = [s_[0] for s_ in multi["stats"]]
+                push = [a["last_push_ms"] for a in st if a["pushes"] > 0]
+                add = [a["last_add_ms"] for a in st if a["collects"] > 0 and a["last_add_ms"] > 0]
+                bytes_push = st[0]["bytes_per_push"]
+                red.update({"bytes_per_push": bytes_push, "pushes_per_projection": world - 1,
+                            "push_ms": float(np.max(push)) if push else None, "push_GBps": bytes_push / (float(np.max(push)) * 1e-3) / 1e9 if push else None,
+                            "fused_add_ms": float(np.max(add)) if add else None,
+                            # what a tracking stream sees of the exchange per projection it OWNS: the fused add (+ a 45 MB memset per
+                            # step on every rank, inside begin(), which the N = 1 step pays as well)
+                            "exposed_ms_per_step_on_the_critical_rank": (float(np.max(add)) if add else 0.0) * (1.0 / world if policy == eng.EXCHANGE_ROTATE else 1.0),
+                            "host_wait_s_per_rank": [a["host_wait_s"] for a in st],
+                            "owner_policy": "rotate" if policy == eng.EXCHANGE_ROTATE else "rank0"})
+            else:
+                red.update({"bytes_per_rank_in_timed_region": reduce_bytes[0], "narrowed_to_u32_when_it_fits": bool(narrow), "algorithm": reduce_algo,
+                            "projections_per_reduction": G})
+            out["reduce"] = red
         if world == 1:
             if not args.no_compat:
                 out["compat"] = compat_leg(ctx, torch, H)
             if not args.no_end_to_end:
-                out["end_to_end"] = end_to_end_scan(ctx, H, workdir)
+                out["end_to_end"] = end_to_end_scan(ctx, H, workdir, n=min(args.scan_projections, nproj))
+                if args.ascii_projections > 0:
+                    out["end_to_end_ascii"] = end_to_end_scan(ctx, H, workdir, n=min(args.ascii_projections, nproj), ascii_files=True)
+            if not args.no_workloads and args.workload == "catphan":
+                out["workloads"] = other_workloads(eng, torch, H, args.projections, device)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only (the other ranks would idle meanwhile)
             base, img_cpu, w2_cpu, n_cpu = cpu_baseline(ctx)
             out["cpu_baseline"] = base
@@ -386,16 +628,24 @@ def main():
             out["atomic_roofline"] = {"bound": "scattered 64-bit atomic adds", "achieved": tally_hits * H / (k_ms * 1e-3) / 1e9, "peak": 23.7,
                                       "unit": "Gatomic/s", "frac": tally_hits * H / (k_ms * 1e-3) / 23.7e9,
                                       "detected_photons_per_history": tally_hits}
-            if world == 1:
-                out["check"].update(oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu))
+            out["check"].update(oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu))
+            failed = failed or not out["check"]["passed"]
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    barrier()
+    if x:
+        torch.cuda.synchronize()
+        barrier()  # nobody unmaps landing memory a peer may still address
+        x.close()
     ctx.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: the correctness check FAILED (see `check` in the line above)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,10 @@ int mcgpu_reload_env_knobs(mcgpu_ctx *ctx);
 /* The same with the full counter set (up to 16): 8 = scheduling points, 9/10 = register<->LDS-slot exchange rounds /
  * lanes that bring a flying history in, 11 = scheduling points in drain mode. */
 int mcgpu_scheduler_stats_ex(mcgpu_ctx *ctx, unsigned long long *out, int capacity, int reset);
+/* Convenience for callers without a HIP binding of their own (ctypes hosts, tests): copy `bytes` from device memory of the
+ * context's device to host memory, ordered behind everything enqueued on `hip_stream` so far; returns when the data is there. */
+int mcgpu_copy_to_host(mcgpu_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes, void *hip_stream);
+
 /* hipMemsetAsync of an image buffer (init_image_array_GPU, MC-GPU_kernel_v1.3.cu:56-72). */
 int mcgpu_clear_image(mcgpu_ctx *ctx, void *image_dev, void *hip_stream);
 
@@ -209,6 +213,37 @@ int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan
  * finalized and written as above.  Tally buffers are double-buffered per device: no device waits for the reduce.  Dose
  * tallies stay per context (sum them with mcgpu_dose_read). */
 int mcgpu_run_scan_multi(mcgpu_ctx *const *ctxs, int n_ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
+
+/* ---- The tally exchange between the GPUs of one node: the sum of the per-rank detector tallies that the reference does with
+ * a device-to-host copy and a blocking MPI_Reduce to rank 0 per projection (MC-GPU_v1.3.cu:1006-1024).  One mcgpu_exchange
+ * per rank -- a process with its own GPU (bench.py, one process per GPU) or a context of one process
+ * (mcgpu_run_scan_multi) -- all built over one small host region `shared` of mcgpu_exchange_shared_bytes(world) ZEROED bytes
+ * that every rank sees (plain memory inside one process, a mapped /dev/shm file between processes).  Every step
+ * (projection) has an owner rank: policy 0 = rank 0, MCGPU_EXCHANGE_ROTATE = step mod world.  Per step, on the rank's
+ * tracking stream:   begin(step) -> tally buffer (zeroed) | mcgpu_launch_projection into it | submit(step) |
+ * collect(step - 1).  submit: a rank that does not own the step pushes its tally into the owner's landing buffer with a COPY
+ * ENGINE (no kernel may run beside the persistent tracking grid), overlapped with the next projection's tracking.
+ * collect: the owner adds the landed tallies to its own in one fused pass behind its next kernel and gets the complete
+ * tally (valid until begin(step + 2)); other ranks get NULL.  Integer sums: the result equals the single-GPU tally bit for
+ * bit.  Between processes ranks swap "cards" (IPC memory and event handles) once: card() on every rank, an all-gather by
+ * whatever means the host has (its process-group library, MPI, a file), connect() to every peer.  A rank that waits for a peer
+ * that has gone gets an error after 120 s, never a hang. */
+typedef struct mcgpu_exchange mcgpu_exchange;
+#define MCGPU_EXCHANGE_ROTATE 1 /* policy bit: owner of step s is rank s % world (default: rank 0, the reference's root) */
+#define MCGPU_EXCHANGE_LOCAL 2  /* policy bit: every rank is a context of THIS process (plain events, connect_local) */
+size_t mcgpu_exchange_shared_bytes(int world);
+size_t mcgpu_exchange_card_bytes(int world);
+int mcgpu_exchange_create(int device_id, int rank, int world, size_t words, int policy, void *shared, mcgpu_exchange **out);
+int mcgpu_exchange_card(mcgpu_exchange *x, unsigned char *card, size_t card_bytes);
+int mcgpu_exchange_connect(mcgpu_exchange *x, int peer, const unsigned char *card, size_t card_bytes);
+int mcgpu_exchange_connect_local(mcgpu_exchange *x, mcgpu_exchange *peer);
+int mcgpu_exchange_owner(const mcgpu_exchange *x, long long step);
+int mcgpu_exchange_begin(mcgpu_exchange *x, long long step, void *hip_stream, void **tally_dev);
+int mcgpu_exchange_submit(mcgpu_exchange *x, long long step, void *hip_stream);
+int mcgpu_exchange_collect(mcgpu_exchange *x, long long step, void *hip_stream, void **reduced_dev);
+/* out6 = {last push [ms], last fused add [ms], pushes, collects, host seconds spent waiting for peers, bytes per push} */
+int mcgpu_exchange_stats(mcgpu_exchange *x, double out6[6]);
+void mcgpu_exchange_destroy(mcgpu_exchange *x);
 
 /* Replace the context's geometry by warp(base geometry, displacement) WITHOUT leaving the device: what
  * MCSimulation4D does per respiratory state with `MCGeometry.warp` + a new voxel file + a new engine process

@@ -91,3 +91,73 @@ def test_two_rank_history_sharding_reduces_to_single_process_image(case_dir, tmp
         want, _ = T.track(0, 42, 0, nbatch, hpt, ol.MATH_PORTABLE)
     assert int(got["histories"][0]) == nbatch * hpt
     assert np.array_equal(got["image"], want)
+
+
+class _FakeExchange:
+    """Stands in for engine.Exchange where there is no GPU: records what the handshake hands it."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.connected = rank, world, {}
+
+    def card(self):
+        return bytes([self.rank]) * 64 * (3 + 2 * self.world)
+
+    def connect(self, peer, card):
+        assert peer != self.rank and peer not in self.connected
+        self.connected[peer] = card
+
+
+def _handshake_worker(rank, world, port, shm_path, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cases
+    eng = cases.pkg.engine
+    # the host region of the exchange: rank 0 creates and zeroes it, the others map it after the barrier (bench.py's order)
+    if rank == 0:
+        m = eng.Exchange.open_shared(shm_path, world, create=True)
+    dist.barrier()
+    if rank != 0:
+        m = eng.Exchange.open_shared(shm_path, world, create=False)
+    assert len(m) == eng.Exchange.shared_bytes(world) and bytes(m[:]) == b"\0" * len(m)
+    fx = _FakeExchange(rank, world)
+    cases.pkg.sharding.connect_exchange(fx, dist)
+    assert sorted(fx.connected) == [r for r in range(world) if r != rank]
+    assert all(card == bytes([peer]) * 64 * (3 + 2 * world) for peer, card in fx.connected.items())
+    # one mapping for everybody: a counter written by one rank is seen by the other
+    m[64 + 8 * rank] = 7 + rank
+    dist.barrier()
+    assert [m[64 + 8 * r] for r in range(world)] == [7 + r for r in range(world)]
+    (Path(out_dir) / f"ok_{rank}").write_text("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_handshake_over_gloo(tmp_path):
+    """The host side of the N > 1 tally exchange that needs no GPU: the mapped counter region (one /dev/shm file, created by
+    rank 0) and the all-gather of the address cards + connect-to-every-peer (sharding.connect_exchange).  The device side
+    (copy-engine pushes, interprocess events, fused add) is covered on the GPU box by tests/test_exchange.py."""
+    world = 2
+    shm = f"/dev/shm/mcgpu_exchange_cputest_{os.getpid()}"
+    port = 31500 + (os.getpid() % 2000)
+    try:
+        mp.spawn(_handshake_worker, args=(world, port, shm, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        Path(shm).unlink(missing_ok=True)
+    assert all((tmp_path / f"ok_{r}").exists() for r in range(world))
+
+
+def test_bench_refuses_a_rank_count_it_cannot_honour():
+    """`bench.py --gpus 2` starts its two rank processes itself (no launcher in the environment) and exits NON-ZERO with a
+    clear message when they cannot run (this container has no GPU); under a launcher that started another number of ranks
+    than --gpus says it refuses to print a mislabelled line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "rank 0 exited" in r.stderr and "rank 1 exited" in r.stderr
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "refusing to run a mislabelled measurement" in r.stderr

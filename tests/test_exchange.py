@@ -1,0 +1,101 @@
+"""The tally exchange between the GPUs of one node (4d-cbct-mc_amd/csrc/exchange.cpp; the reference's MPI_Reduce of the
+detector images, MC-GPU_v1.3.cu:1006-1024): copy-engine pushes into the owner's landing buffer, one fused add.  History ids
+own their RNG streams and tallies are integers, so the summed sharded tally must equal one rank simulating the same ids alone
+BIT FOR BIT -- between contexts of one process (what mcgpu_run_scan_multi runs) and between processes over IPC handles and
+interprocess events (what bench.py's ranks run; here two processes on the one GPU of the box)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+
+HERE = Path(__file__).resolve().parent
+
+
+def test_exchange_sizes_and_argument_checks(engine):
+    lib = engine.load_library()
+    assert lib.mcgpu_exchange_card_bytes(8) == 64 * (1 + 2 + 16)
+    assert engine.Exchange.shared_bytes(8) > engine.Exchange.shared_bytes(2) > 0
+    with pytest.raises(engine.EngineError):  # no device in this process / bad world: an error return, not a crash
+        engine.Exchange(0, 5, 2, 1024, bytearray(engine.Exchange.shared_bytes(2)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,policy", [(3, "rotate"), (2, "rank0"), (1, "rotate")])
+def test_exchange_between_contexts_of_one_process(engine, case_dir, world, policy):
+    inp = case_dir("catphan64_ct")
+    pol = (engine.EXCHANGE_ROTATE if policy == "rotate" else engine.EXCHANGE_ROOT0) | engine.EXCHANGE_LOCAL
+    steps, hist = 9, 150_000
+    shared = bytearray(engine.Exchange.shared_bytes(world))
+    ctxs = [engine.create(inp, device=0) for _ in range(world)]
+    xs = []
+    try:
+        xs = [engine.Exchange(0, r, world, ctxs[0].image_words, shared, pol) for r in range(world)]
+        for a in xs:
+            for b in xs:
+                if a is not b:
+                    a.connect_local(b)
+        nproj, seed = ctxs[0].num_projections, ctxs[0].geti("seed")
+        reduced = {}
+        for k in range(steps + 1):
+            if k < steps:
+                for r in range(world):
+                    tally = xs[r].begin(k)
+                    ctxs[r].launch(k % nproj, tally, hist, mode="fast", seed=seed, first=r * hist)
+                    xs[r].submit(k)
+            if k > 0:
+                owner = xs[0].owner(k - 1)
+                assert owner == ((k - 1) % world if policy == "rotate" else 0)
+                for r in range(world):
+                    got = xs[r].collect(k - 1)
+                    assert bool(got) == (r == owner)
+                    if got:
+                        reduced[k - 1] = ctxs[r].download_image(got)
+        for k in range(steps):
+            alone, _, _ = ctxs[0].run_projection(k % nproj, world * hist, mode="fast", seed=seed, first=0)
+            assert np.array_equal(reduced[k], alone) and alone.sum() > 0, k
+        with pytest.raises(engine.EngineError):  # a step is collected once
+            xs[0].collect(steps - 1)
+        if world > 1:
+            st = [x.stats() for x in xs]
+            assert sum(s["pushes"] for s in st) == steps * (world - 1) and sum(s["collects"] for s in st) == steps
+    finally:
+        for x in xs:
+            x.close()
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [1, 0])
+def test_exchange_between_two_processes_on_one_gpu(engine, case_dir, tmp_path, policy):
+    """IPC memory handles + interprocess events: two rank processes (fresh interpreters) share the box's GPU."""
+    inp = case_dir("catphan64_ct")
+    world, steps, hist = 2, 7, 200_000
+    shm = Path("/dev/shm") / f"mcgpu_exchange_test_{os.getpid()}_{policy}"
+    engine.Exchange.open_shared(shm, world, create=True).close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        procs = [subprocess.Popen([sys.executable, str(HERE / "exchange_rank.py"), str(inp), str(r), str(world), str(policy), str(steps), str(hist), str(shm),
+                                   str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                out, _ = p.communicate()
+            outs.append(out.decode(errors="replace"))
+        assert all(p.returncode == 0 for p in procs), outs
+    finally:
+        shm.unlink(missing_ok=True)
+    with engine.create(inp, device=0) as ctx:
+        nproj, seed = ctx.num_projections, ctx.geti("seed")
+        for k in range(steps):
+            alone, _, _ = ctx.run_projection(k % nproj, world * hist, mode="fast", seed=seed, first=0)
+            got = np.load(tmp_path / f"reduced_{k}.npy")
+            assert np.array_equal(got, alone) and alone.sum() > 0, k
