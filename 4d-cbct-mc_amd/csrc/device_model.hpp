@@ -1,10 +1,15 @@
 // device_model.hpp -- device-resident tables of the photon-history kernel and its launch arguments.
 //
 // HBM layout (DESIGN.md "Data layout"):
-//   volume    : palette index per voxel, x fastest (u8 when the volume holds <=256 distinct
-//               (material,density) pairs, u16 up to 65536, else raw {density, material} float2).
-//               512^3 Catphan604 -> 128 MiB (fits the 256 MiB Infinity Cache) instead of the
-//               reference's 1 GiB float2 array (MC-GPU_v1.3.cu:2135-2137).
+//   volume    : palette index per voxel (u8 when the volume holds <=256 distinct (material,density) pairs, u16 up to
+//               65536, else raw {density, material} float2).  512^3 Catphan604 -> 128 MiB (fits the 256 MiB Infinity
+//               Cache) instead of the reference's 1 GiB float2 array (MC-GPU_v1.3.cu:2135-2137).
+//               u8 volumes are stored in TILES of 4x4x4 voxels: tile t = sub-brick index (x fastest over the sub-brick
+//               grid), voxel (ix,iy,iz) at byte 64 t + (iz&3) 16 + (iy&3) 4 + (ix&3) (tiled_voxel below).  A tile is one
+//               64-byte memory sector and exactly one sub-brick of the second brick level, so the only tiles ever fetched are
+//               the MIXED sub-bricks -- the material boundaries -- and each arrives whole: with x-fastest rows a sector was a
+//               64x1x1 needle, a mixed sub-brick touched 16 of them, and the fetched set was many times the boundary voxels
+//               (thorax: 963 B of fabric traffic per history against 356 algorithmic, round-2 PMC).  u16 / raw: x fastest.
 //   palette   : float2 {density, bits(compact material index)}  (staged in LDS when <=256 entries)
 //   bricks    : 4 bits per brick of (2^k)^3 voxels, <= 32768 bricks (16 KiB), LDS-resident: code c < 14 when all
 //               voxels of the brick share one palette entry (brick_palette[c], the 14 most frequent such entries),
@@ -13,9 +18,9 @@
 //               body) and never touch the volume.
 //   sub       : the same 4-bit codes per sub-brick of 4^3 voxels, dense over the volume (0.5 MB for 512x512x256), L2-resident:
 //               asked by a flight step that lands in a mixed brick before it asks the volume (FAST kernel)
-//   mfp_tot   : per (energy bin, compact material) float2 {a_tot, b_tot}: 1.9 MB, L2-resident; the FAST flight step reads
+//   mfp_tot   : per (compact material, energy bin) -- material-major rows -- float2 {a_tot, b_tot}: 1.9 MB, L2-resident; the FAST flight step reads
 //               only this (virtual-or-real test); the kind of a real interaction is drawn later, in a batch
-//   mfp       : per (energy bin, compact material) one 32-byte record
+//   mfp       : per (compact material, energy bin) one 32-byte record
 //               {a_tot, a_Co, a_Ra, b_tot | b_Co, b_Ra, pmax(bin+1), 0}  -- one aligned 32-B fetch where the
 //               reference reads 2 x float3 from two 7.2 MB tables plus pmax from a third (K.cu:268-269,336).
 //   woodcock  : float2 {a,b} per energy bin (K.cu:228)
@@ -29,6 +34,13 @@
 namespace mcgpu {
 
 enum VolumeKind : int { kVolU8 = 0, kVolU16 = 1, kVolRaw = 2 };
+// byte offset of voxel (ix, iy, iz) in a tiled u8 volume whose sub-brick grid is sub_nx wide and sub_nxy per slab
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned int tiled_voxel(unsigned int ix, unsigned int iy, unsigned int iz, unsigned int sub_nx, unsigned int sub_nxy) {
+  return ((((ix >> 2) + (iy >> 2) * sub_nx + (iz >> 2) * sub_nxy)) << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u);
+}
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
@@ -105,8 +117,8 @@ struct TrackArgs {
   float e0, ide;
   int num_values, nmat;
   const float* woodcock;  // float2[num_values]
-  const float* mfp;       // 8 floats per (bin*nmat + mc)
-  const float* mfp_tot;   // float2 {a_tot, b_tot} per (bin*nmat + mc): the only cross section a flight step needs (FAST)
+  const float* mfp;       // 8 floats per row mc*num_values + bin (track_common.inc: table_row)
+  const float* mfp_tot;   // float2 {a_tot, b_tot} per row mc*num_values + bin: the only cross section a flight step needs (FAST)
   int sig_shift;          // FAST: coarse energy bin = bin >> sig_shift for the LDS brackets of mfp_tot; -1 = no brackets
   const TrackCold* cold;
   int nbins;

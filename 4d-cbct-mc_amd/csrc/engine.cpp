@@ -291,12 +291,30 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     D.palette_host = palette;
     std::vector<uint8_t> idx8(nvox);
     for (size_t i = 0; i < nvox; ++i) idx8[i] = (uint8_t)idx16[i];
-    D.vol = D.put(idx8);
-    D.vol_bytes = nvox;
     D.palette_size = (int)index_of.size();
     D.palette = D.put(palette);
     // brick grid: smallest power-of-two brick (>= 4 voxels) that keeps the grid within the LDS budget
     const int nx = H.voxels.n[0], ny = H.voxels.n[1], nz = H.voxels.n[2];
+    {
+      // device layout: tiles of 4x4x4 voxels = one 64-byte sector = one sub-brick of the second level (device_model.hpp:
+      // tiled_voxel); the padding voxels of edge tiles repeat the tile's first voxel and are never addressed
+      const unsigned int snx = (unsigned int)((nx + 3) >> 2), sny = (unsigned int)((ny + 3) >> 2), snz = (unsigned int)((nz + 3) >> 2);
+      const size_t tiles = (size_t)snx * sny * snz;
+      if (tiles * 64 >= (1ULL << 31)) throw Error(-2, "!!ERROR!! voxel grid too large for the 32-bit voxel index of the kernel");
+      std::vector<uint8_t> tiled(tiles * 64);
+      for (size_t t = 0; t < tiles; ++t) {
+        const int x0 = (int)(t % snx) << 2, y0 = (int)((t / snx) % sny) << 2, z0 = (int)(t / ((size_t)snx * sny)) << 2;
+        const uint8_t pad = idx8[((size_t)z0 * ny + y0) * nx + x0];
+        for (int dz = 0; dz < 4; ++dz)
+          for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx) {
+              const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+              tiled[t * 64 + (size_t)(dz * 16 + dy * 4 + dx)] = (x < nx && y < ny && z < nz) ? idx8[((size_t)z * ny + y) * nx + x] : pad;
+            }
+      }
+      D.vol = D.put(tiled);
+      D.vol_bytes = tiled.size();
+    }
     int k = 2;
     auto nb = [&](int n, int sh) { return (n + (1 << sh) - 1) >> sh; };
     const char* mb = getenv("MCGPU_MAX_BRICKS");  // tuning knob: a coarser grid frees LDS
@@ -438,7 +456,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     for (int m = 0; m < kMaxMaterials; ++m) {
       const int mc = D.compact_of[m];
       if (mc < 0) continue;
-      float* r = &rec[8 * ((size_t)i * nmat + mc)];
+      float* r = &rec[8 * ((size_t)mc * nv + i)];  // material-major rows (track_common.inc: table_row)
       const Float3& a = H.mat.a[(size_t)i * kMaxMaterials + m];
       const Float3& b = H.mat.b[(size_t)i * kMaxMaterials + m];
       r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
@@ -572,7 +590,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       for (int mc = 0; mc < nmat; ++mc) {
         double lo = 1e300, hi = -1e300;
         for (int i = c << shift; i < std::min(nv, (c + 1) << shift); ++i) {
-          const double a = D.sig_tot_host[2 * ((size_t)i * nmat + mc)], b = D.sig_tot_host[2 * ((size_t)i * nmat + mc) + 1];
+          const double a = D.sig_tot_host[2 * ((size_t)mc * nv + i)], b = D.sig_tot_host[2 * ((size_t)mc * nv + i) + 1];
           // the kernel evaluates a + b * E for E in [E_i, E_{i+1}) (one table bin; a little beyond for float rounding)
           const double ea = e0 + (i - 0.01) / ide, eb = e0 + (i + 1.01) / ide;
           lo = std::min(lo, std::min(a + b * ea, a + b * eb));
@@ -681,7 +699,15 @@ void sync_host_voxels(mcgpu_ctx& C) {
   HIP_TRY(hipSetDevice(D.device_id));
   const size_t nvox = H.voxels.count();
   std::vector<unsigned char> idx(nvox);
-  HIP_TRY(hipMemcpy(idx.data(), D.vol, nvox, hipMemcpyDeviceToHost));
+  {  // the device volume is tiled (device_model.hpp: tiled_voxel)
+    std::vector<unsigned char> tiled(D.vol_bytes);
+    HIP_TRY(hipMemcpy(tiled.data(), D.vol, D.vol_bytes, hipMemcpyDeviceToHost));
+    const int nx = H.voxels.n[0], ny = H.voxels.n[1], nz = H.voxels.n[2];
+    const unsigned int snx = (unsigned int)D.sub_n[0], snxy = (unsigned int)(D.sub_n[0] * D.sub_n[1]);
+    for (int z = 0; z < nz; ++z)
+      for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) idx[((size_t)z * ny + y) * nx + x] = tiled[tiled_voxel((unsigned)x, (unsigned)y, (unsigned)z, snx, snxy)];
+  }
   int mat_of[256];
   float dens_of[256];
   for (int e = 0; e < D.palette_size; ++e) {
@@ -1402,8 +1428,8 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
   const size_t nvox = H.voxels.count();
   const size_t nsub = (size_t)D.sub_n[0] * D.sub_n[1] * D.sub_n[2];
   if (!D.vol_base) {  // first call: what is resident now is the base geometry of every later warp
-    D.vol_base = D.put(std::vector<unsigned char>(nvox, 0));
-    HIP_TRY(hipMemcpy(D.vol_base, D.vol, nvox, hipMemcpyDeviceToDevice));
+    D.vol_base = D.put(std::vector<unsigned char>(D.vol_bytes, 0));
+    HIP_TRY(hipMemcpy(D.vol_base, D.vol, D.vol_bytes, hipMemcpyDeviceToDevice));
     D.sub_first = D.put(std::vector<unsigned short>(nsub, 0));
     D.brick_first = D.put(std::vector<unsigned short>((size_t)D.brick_count, 0));
     D.code_of_dev = D.put(std::vector<unsigned char>(D.code_of, D.code_of + 256));

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 
+#include "device_model.hpp"
 #include "geometry_device.hpp"
 
 namespace mcgpu {
@@ -37,26 +38,33 @@ __device__ __forceinline__ float nearest_sample(float loc, int n) {
 //          (x, y, z) is geometry voxel (gx, gy, gz) = (ny - 1 - y, x, z).  The warp is evaluated in the geometry's frame,
 //          where the reference evaluates it (ties and border samples do not survive a mirrored axis), and only the
 //          result is addressed in the engine's layout.
+// Source and destination are TILED index volumes (device_model.hpp: tiled_voxel).  One thread per voxel of the padded
+// grid, in tile order: a wave writes one whole 64-byte tile (the padding voxels of edge tiles get the default).
 template <int FRAME>
-__global__ __launch_bounds__(256) void warp_index_kernel(int nx, int ny, int nz, const unsigned char* __restrict__ base, const float* __restrict__ dvf,
-                                                         unsigned char default_index, unsigned char* __restrict__ out) {
-  const size_t nvox = (size_t)nx * ny * nz;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((size_t)nx * ny));
+__global__ __launch_bounds__(256) void warp_index_kernel(int nx, int ny, int nz, int snx, int sny, int snz, const unsigned char* __restrict__ base,
+                                                         const float* __restrict__ dvf, unsigned char default_index, unsigned char* __restrict__ out) {
+  const size_t nvox = (size_t)nx * ny * nz, ncell = (size_t)snx * sny * snz * 64;
+  const unsigned int snxy = (unsigned int)(snx * sny);
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = c >> 6;
+    const int x = ((int)(t % snx) << 2) | (int)(c & 3), y = ((int)((t / snx) % sny) << 2) | (int)((c >> 2) & 3), z = ((int)(t / snxy) << 2) | (int)((c >> 4) & 3);
     unsigned char v = default_index;
-    if (FRAME == 0) {
-      const float sx = nearest_sample((float)x + dvf[i], nx), sy = nearest_sample((float)y + dvf[nvox + i], ny), sz = nearest_sample((float)z + dvf[2 * nvox + i], nz);
-      if (sx >= 0.f && sx <= (float)(nx - 1) && sy >= 0.f && sy <= (float)(ny - 1) && sz >= 0.f && sz <= (float)(nz - 1))
-        v = base[(size_t)(int)sx + (size_t)(int)sy * nx + (size_t)(int)sz * nx * ny];
-    } else {
-      const int g0 = ny, g1 = nx, g2 = nz;  // extents of the geometry arrays
-      const int gx = ny - 1 - y, gy = x, gz = z;
-      const size_t f = ((size_t)gx * g1 + gy) * g2 + gz;
-      const float sx = nearest_sample((float)gx + dvf[f], g0), sy = nearest_sample((float)gy + dvf[nvox + f], g1), sz = nearest_sample((float)gz + dvf[2 * nvox + f], g2);
-      if (sx >= 0.f && sx <= (float)(g0 - 1) && sy >= 0.f && sy <= (float)(g1 - 1) && sz >= 0.f && sz <= (float)(g2 - 1))
-        v = base[(size_t)(int)sy + (size_t)(ny - 1 - (int)sx) * nx + (size_t)(int)sz * nx * ny];
+    if (x < nx && y < ny && z < nz) {
+      if (FRAME == 0) {
+        const size_t i = (size_t)x + (size_t)y * nx + (size_t)z * nx * ny;
+        const float sx = nearest_sample((float)x + dvf[i], nx), sy = nearest_sample((float)y + dvf[nvox + i], ny), sz = nearest_sample((float)z + dvf[2 * nvox + i], nz);
+        if (sx >= 0.f && sx <= (float)(nx - 1) && sy >= 0.f && sy <= (float)(ny - 1) && sz >= 0.f && sz <= (float)(nz - 1))
+          v = base[tiled_voxel((unsigned int)(int)sx, (unsigned int)(int)sy, (unsigned int)(int)sz, (unsigned int)snx, snxy)];
+      } else {
+        const int g0 = ny, g1 = nx, g2 = nz;  // extents of the geometry arrays
+        const int gx = ny - 1 - y, gy = x, gz = z;
+        const size_t f = ((size_t)gx * g1 + gy) * g2 + gz;
+        const float sx = nearest_sample((float)gx + dvf[f], g0), sy = nearest_sample((float)gy + dvf[nvox + f], g1), sz = nearest_sample((float)gz + dvf[2 * nvox + f], g2);
+        if (sx >= 0.f && sx <= (float)(g0 - 1) && sy >= 0.f && sy <= (float)(g1 - 1) && sz >= 0.f && sz <= (float)(g2 - 1))
+          v = base[tiled_voxel((unsigned int)(int)sy, (unsigned int)(ny - 1 - (int)sx), (unsigned int)(int)sz, (unsigned int)snx, snxy)];
+      }
     }
-    out[i] = v;
+    out[c] = v;
   }
 }
 
@@ -73,9 +81,10 @@ __global__ __launch_bounds__(256) void classify_sub_kernel(GeometryRebuild g) {
     const int x1 = min(x0 + 4, g.nx), y1 = min(y0 + 4, g.ny), z1 = min(z0 + 4, g.nz);
     int first = -1;
     bool mixed = false;
+    const unsigned char* tile = g.idx + ((size_t)s << 6);  // the sub-brick's own 64-byte tile
     for (int z = z0; z < z1; ++z)
       for (int y = y0; y < y1; ++y) {
-        const unsigned char* row = g.idx + ((size_t)z * g.ny + y) * g.nx;
+        const unsigned char* row = tile + ((z & 3) << 4) + ((y & 3) << 2) - x0;
         for (int x = x0; x < x1; ++x) {
           const int v = row[x];
           if (first < 0) first = v;
@@ -153,10 +162,12 @@ __global__ void init_out_kernel(unsigned int* out) {
 }  // namespace
 
 hipError_t launch_geometry_rebuild(const GeometryRebuild& g, int warp_frame, bool allow_exterior, hipStream_t stream) {
-  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
-  const unsigned wblocks = (unsigned)std::min<size_t>((nvox + 255) / 256, 256u * 64u);
-  if (warp_frame == 0) hipLaunchKernelGGL(warp_index_kernel<0>, dim3(wblocks), dim3(256), 0, stream, g.nx, g.ny, g.nz, g.base_idx, g.dvf, g.default_index, g.idx);
-  else if (warp_frame == 1) hipLaunchKernelGGL(warp_index_kernel<1>, dim3(wblocks), dim3(256), 0, stream, g.nx, g.ny, g.nz, g.base_idx, g.dvf, g.default_index, g.idx);
+  const size_t ncell = (size_t)g.sn[0] * g.sn[1] * g.sn[2] * 64;
+  const unsigned wblocks = (unsigned)std::min<size_t>((ncell + 255) / 256, 256u * 64u);
+  if (warp_frame == 0)
+    hipLaunchKernelGGL(warp_index_kernel<0>, dim3(wblocks), dim3(256), 0, stream, g.nx, g.ny, g.nz, g.sn[0], g.sn[1], g.sn[2], g.base_idx, g.dvf, g.default_index, g.idx);
+  else if (warp_frame == 1)
+    hipLaunchKernelGGL(warp_index_kernel<1>, dim3(wblocks), dim3(256), 0, stream, g.nx, g.ny, g.nz, g.sn[0], g.sn[1], g.sn[2], g.base_idx, g.dvf, g.default_index, g.idx);
   hipLaunchKernelGGL(init_out_kernel, dim3(1), dim3(32), 0, stream, g.out);
   const int nsub = g.sn[0] * g.sn[1] * g.sn[2], nb = g.bn[0] * g.bn[1] * g.bn[2];
   hipLaunchKernelGGL(classify_sub_kernel, dim3((nsub + 255) / 256), dim3(256), 0, stream, g);

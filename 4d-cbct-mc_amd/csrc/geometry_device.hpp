@@ -8,10 +8,10 @@ struct GeometryRebuild {
   int nx, ny, nz;
   int brick_shift, bn[3];           // first level: bricks of (2^brick_shift)^3 voxels
   int sn[3];                        // second level: sub-bricks of 4^3 voxels
-  const unsigned char* base_idx;    // palette index volume of the base geometry (warp source)
+  const unsigned char* base_idx;    // palette index volume of the base geometry, tiled 4x4x4 like the live one (warp source)
   const float* dvf;                 // displacement field in voxels, 3 x nvox floats (layout: warp_frame)
   unsigned char default_index;      // palette index of the default (material, density) for samples from outside
-  unsigned char* idx;               // palette index volume the kernels read from now on (warp destination)
+  unsigned char* idx;               // tiled palette index volume the kernels read from now on (warp destination)
   unsigned short* sub_first;        // scratch [sub-bricks]: palette entry or 0x100 = mixed
   unsigned short* brick_first;      // scratch [bricks]
   unsigned char* sub;               // 4-bit codes of the sub-bricks, two per byte (null: level not in use)

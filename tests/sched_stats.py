@@ -33,7 +33,10 @@ with eng.create(inp, device=0) as ctx:
                                              "shell_lanes_per_round": round(s["compton_shell_lanes"] / max(s["compton_rounds"], 1), 1),
                                              "done_per_round": round(s["compton_done_lanes"] / max(s["compton_rounds"], 1), 1)},
                           "pool_after_sched_point": {k: round(s[k] / max(s["scheduling_points"], 1), 1) for k in
-                                                     ("pool_flyable", "pool_wants_new", "pool_compton", "lanes_idle", "lanes_both_flyable")},
+                                                     ("pool_flyable", "pool_wants_new", "pool_compton", "lanes_both_flyable")},
+                          "per_history": {"flight_steps": round(s["flying_lanes"] / done, 3), "voxel_loads": round(s["voxel_load_lanes"] / done, 3),
+                                          "exact_sigma_loads": round(s["sigma_load_lanes"] / done, 3),
+                                          "real_records": round((s["compton_done_lanes"]) / done, 3)},
                           "flight_loads": {"iter_with_voxel_load": round(s["iter_with_voxel_load"] / it, 3), "voxel_lanes_per_iter": round(s["voxel_load_lanes"] / it, 2),
                                            "iter_with_sigma_load": round(s["iter_with_sigma_load"] / it, 3), "sigma_lanes_per_iter": round(s["sigma_load_lanes"] / it, 2)},
                           "cycles_per_hist": {k[7:]: round(s[k] / done, 1) for k in ("cycles_flight", "cycles_compton", "cycles_rayleigh", "cycles_new")},

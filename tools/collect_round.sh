@@ -8,7 +8,7 @@ TAG=${1:-r03}; OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 cd "$ROOT"
 mkdir -p "$OUT"
-LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat"
+LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads"
 bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json; cp $OUT/pmc/summary.json profiles/pmc_summary_latest.json
 for wl in thorax cirs; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err

@@ -48,11 +48,32 @@ def exchanged():
     exchanged.k = base + steps
     return ms[4:], push, add
 exchanged.k = 0
+import ctypes, time
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+src = torch.ones((4, nz, nx), dtype=torch.int64, device="cuda"); dst = torch.zeros_like(src)
+def copy_beside(kind):
+    """one 45 MB device-to-device copy of `kind` (3 = a kernel, 1024 = copy engine) issued 0.5 ms into each tracking launch"""
+    ms, cp = [], []
+    for i in range(steps):
+        ctx.clear(image.data_ptr(), stream)
+        ctx.launch((i * 149) % nproj, image.data_ptr(), H, mode="fast", seed=seed, stream=stream)
+        time.sleep(0.0005)
+        t0 = time.perf_counter()
+        hip.hipMemcpyAsync(dst.data_ptr(), src.data_ptr(), src.numel() * 8, kind, side.cuda_stream)
+        hip.hipStreamSynchronize(side.cuda_stream)
+        cp.append((time.perf_counter() - t0) * 1e3)
+        ms.append(ctx.last_kernel_ms())
+    return float(np.mean(ms[4:])), float(np.mean(cp[4:]))
 a = plain(); (b, push, add) = exchanged(); c = plain(); (d, push2, add2) = exchanged()
 torch.cuda.synchronize()
+k_sdma, c_sdma = copy_beside(1024); k_blit, c_blit = copy_beside(3); e = plain()
 out = {"histories_per_step": H, "kernel_ms_plain": [float(np.mean(a)), float(np.mean(c))], "kernel_ms_with_exchange": [float(np.mean(b)), float(np.mean(d))],
        "push_ms_beside_the_next_kernel": float(np.mean(push + push2)), "push_GBps": ctx.image_words * 8 / (float(np.mean(push + push2)) * 1e-3) / 1e9,
-       "fused_add_ms_one_peer": float(np.mean(add + add2)), "steps_per_series": steps - 4}
+       "fused_add_ms_one_peer_starved_beside_the_tracking_kernel_of_the_same_device": float(np.mean(add + add2)), "steps_per_series": steps - 4,
+       "copy_engine_45MB_beside_tracking": {"kernel_ms": k_sdma, "copy_ms_host_timed": c_sdma, "GBps": src.numel() * 8 / (c_sdma * 1e-3) / 1e9},
+       "blit_kernel_45MB_beside_tracking": {"kernel_ms": k_blit, "copy_ms_host_timed": c_blit}, "kernel_ms_plain_again": float(np.mean(e))}
 print(json.dumps(out))
 for x in xs: x.close()
 owner_ctx.close(); ctx.close()
