@@ -427,12 +427,15 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       // gathers of the flight step were what bound that workload (1.45 KB of fabric traffic per history at 5e9 histories/s).
       std::vector<unsigned char> sub((nsub + 1) / 2, 0xFF);
       D.sub_mixed = 0;
-      // Worth its dependent L2 round trip only where most bricks a photon meets are mixed (body-filling volumes: 61 % of
-      // the bricks inside the object box of the thorax workload, +24 %; Catphan 43 %: -1.5 %, CIRS with its 8^3 bricks 28 %:
-      // -7 %); MCGPU_SUB_BRICKS=0/1 overrides.
-      const long inside = (long)D.brick_count - D.bricks_exterior;
+      // Round 2 (x-fastest rows): worth its dependent L2 round trip where most bricks a photon meets are mixed (thorax +24 %).
+      // Round 3: the volume is stored in 4x4x4 TILES, one tile = one 64-byte sector = one sub-brick -- asking the volume
+      // directly now costs one sector like asking this table, without the second dependent round trip, and the tile it
+      // brings in serves the neighbouring voxels of later photons.  Measured on one box (tools/batch_e.sh): thorax 14.27
+      // -> 13.68 ms, CIRS 6.52 -> 6.25, Catphan 4.17 -> 4.09 with the table OFF.  So it is off unless MCGPU_SUB_BRICKS=1
+      // asks for it (kept: it halves the fabric traffic where that is what binds, and the tests hold both routes to the
+      // same tallies).
       const char* knob = getenv("MCGPU_SUB_BRICKS");
-      const bool off = knob ? atoi(knob) == 0 : !(inside > 0 && 2L * D.bricks_mixed > inside);
+      const bool off = knob ? atoi(knob) == 0 : true;
       for (size_t b = 0; b < nsub; ++b) {
         const int code = (!off && first2[b] >= 0 && first2[b] < 0x100) ? code_of[first2[b]] : 0xF;
         D.sub_mixed += (code == 0xF);

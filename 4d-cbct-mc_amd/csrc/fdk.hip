@@ -6,6 +6,8 @@
 //                 short side to a detector symmetric about the central ray                                     (streaming)
 //   ramp        : rows zero-extended to L = 4096, batched hipFFT R2C -> multiply by the real spectrum of the (Hann-apodised)
 //                 ramp -> C2R (HBM streaming); ramp_rows = the direct LDS convolution kept for A/B (MCGPU_FDK_DIRECT_RAMP)
+//   extend_rows : --pad (RTK TruncationCorrection): every row continued on both sides by next = ceil(pad x width) columns with
+//                 the feathered point reflection 2 p(border) - p(mirror), so that a truncated edge does not ring     (streaming)
 //   smooth_cols : --hannY low-pass along v (3 taps for 1.0)                                                     (streaming)
 //   backproject : voxel-driven, bilinear; a thread owns one (x, z) column of the volume, precomputes everything that does
 //                 not depend on y for a batch of 8 projections in registers, then walks y: 4 loads + 10 flops per update;
@@ -61,6 +63,18 @@ __global__ void weight_kernel(const float* __restrict__ in, float* __restrict__ 
     v *= sdd / sqrtf(sdd * sdd + up * up + vp * vp) * w_dis[(size_t)k * nu + iu];
   }
   out[i] = v;
+}
+
+// rtkfdk --pad (rtk::FFTProjectionsConvolutionImageFilter::PadInputImageRegion with TruncationCorrection > 0; restated in
+// oracle/fdk_oracle.py: truncation_extension).  A row occupies columns [next, next + n) of its buffer row; the columns at
+// distance d = 1..next beyond either border get w[d] * (2 p(border) - p(border -/+ d)).  One thread per (row, d).
+__global__ void extend_rows_kernel(float* __restrict__ rows, int stride, int n, int next, size_t n_rows, const float* __restrict__ w /*[next + 1]*/) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * (size_t)next) return;
+  const int d = (int)(i % next) + 1;
+  float* row = rows + (i / next) * (size_t)stride + next;
+  row[-d] = w[d] * (2.0f * row[0] - row[d]);
+  row[n - 1 + d] = w[d] * (2.0f * row[n - 1] - row[n - 1 - d]);
 }
 
 // out[row][i] = scale * sum_j in[row][j] * h[i - j + nu - 1];  one block per row, 256 threads, 4 consecutive outputs per thread
@@ -121,6 +135,7 @@ __global__ void spectrum_kernel(float2* __restrict__ spec, const float* __restri
 
 struct BackArgs {
   int nx, ny, nz, nu, nv, nb;  // nb = projections in this batch; nu = usable columns
+  int u_first;                 // column of the buffer rows that holds detector column 0 (the --pad extension lies before it)
   int stride;                  // floats per detector row in q
   float x0, y0, z0, sx, sy, sz;
   float sid, sdd, inv_du, inv_dv, u0, v0;
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void backproject_kernel(float* __restrict__
         const int iv = (int)fl;
         if (iv >= 0 && iv < A.nv - 1) {
           const float av = fv - fl;
-          const float* r0 = q + (size_t)k * plane + (size_t)iv * A.stride + iu[k];
+          const float* r0 = q + (size_t)k * plane + (size_t)iv * A.stride + A.u_first + iu[k];
           float2 lo, hi;  // (iu, iu + 1) of both rows with one 8-byte load each (4-byte aligned: global loads need no more)
           __builtin_memcpy(&lo, r0, 8);
           __builtin_memcpy(&hi, r0 + A.stride, 8);
@@ -285,7 +300,7 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
   }
   float2* d_spec = nullptr;
   hipfftHandle plan_fwd = 0, plan_inv = 0;
-  float *d_free_raw = nullptr, *d_in = nullptr, *d_tmp = nullptr, *d_vol = nullptr, *d_h = nullptr, *d_ky = nullptr, *d_wdis = nullptr, *d_wpc = nullptr;
+  float *d_free_raw = nullptr, *d_free_wext = nullptr, *d_in = nullptr, *d_tmp = nullptr, *d_vol = nullptr, *d_h = nullptr, *d_ky = nullptr, *d_wdis = nullptr, *d_wpc = nullptr;
   ProjParam* d_pp = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   int rc = 0;
@@ -353,12 +368,16 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     }
     const int nu_p = nu + pad_l + pad_r;
     const double u0_p = o->u0 - pad_l * o->du;
+    // rtkfdk --pad: the ramp sees rows of nu_e = nu_p + 2 next columns (extend_rows_kernel); the back-projector only the nu_p
+    // detector columns in their middle
+    const int next = (o->pad > 0.0) ? std::min((int)std::ceil(o->pad * nu_p), nu_p - 1) : 0;
+    const int nu_e = nu_p + 2 * next;
     // Ramp filter: FFT (hipFFT, rows zero-extended to L >= 2 nu_p - 1: no wrap-around inside the nu_p columns that are used) or,
     // with MCGPU_FDK_DIRECT_RAMP, the direct LDS convolution (same result up to float rounding; tests compare both to the oracle)
     const bool direct = getenv("MCGPU_FDK_DIRECT_RAMP") != nullptr;
     int L = 1;
-    while (L < 2 * nu_p - 1) L *= 2;
-    const int stride = direct ? nu_p : L;        // floats per detector row in the filtered buffers
+    while (L < 2 * nu_e - 1) L *= 2;
+    const int stride = direct ? nu_e : L;        // floats per detector row in the filtered buffers
     const int nk = L / 2 + 1;
     const size_t plane_p = (size_t)stride * nv;
     const int chunk = std::min(n, direct ? 64 : 32);  // projections resident on the device at a time (multiple of kBatch)
@@ -369,7 +388,15 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     FDK_HIP(hipMalloc(&d_tmp, (size_t)chunk * plane_p * 4));
     FDK_HIP(hipMalloc(&d_vol, nvox * 4));
     FDK_HIP(hipMemset(d_vol, 0, nvox * 4));
-    const std::vector<double> hd = ramp_kernel(nu_p - 1, o->hann);
+    const std::vector<double> hd = ramp_kernel(nu_e - 1, o->hann);
+    float* d_wext = nullptr;
+    if (next > 0) {
+      std::vector<float> wext((size_t)next + 1, 0.f);
+      for (int d = 1; d <= next; ++d) wext[(size_t)d] = next > 1 ? (float)std::pow(std::sin((double)(next - d) * M_PI / (2.0 * next - 2.0)), 0.75) : 0.f;
+      FDK_HIP(hipMalloc(&d_wext, wext.size() * 4));
+      d_free_wext = d_wext;
+      FDK_HIP(hipMemcpy(d_wext, wext.data(), wext.size() * 4, hipMemcpyHostToDevice));
+    }
     const double scale = (o->sdd / o->sid) / o->du;
     if (direct) {
       std::vector<float> h(hd.begin(), hd.end());
@@ -379,7 +406,7 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
       // spectrum of the kernel laid out circularly (lag n at index n mod L); real because the kernel is even;
       // the scale of the filter and hipFFT's missing 1/L are folded in
       std::vector<std::complex<double>> c((size_t)L, 0.0);
-      for (int lag = -(nu_p - 1); lag <= nu_p - 1; ++lag) c[(size_t)((lag + L) % L)] = hd[(size_t)(lag + nu_p - 1)];
+      for (int lag = -(nu_e - 1); lag <= nu_e - 1; ++lag) c[(size_t)((lag + L) % L)] = hd[(size_t)(lag + nu_e - 1)];
       fft(c, false);
       std::vector<float> H((size_t)nk);
       for (int k = 0; k < nk; ++k) H[(size_t)k] = (float)(c[(size_t)k].real() * scale / (double)L);
@@ -401,7 +428,7 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     }
     FDK_HIP(hipEventCreate(&e0)); FDK_HIP(hipEventCreate(&e1)); FDK_HIP(hipEventCreate(&e2)); FDK_HIP(hipEventCreate(&e3));
     double ms_filter = 0.0, ms_back = 0.0;
-    const size_t lds_ramp = ((size_t)nu_p + 2 * nu_p + 2) * 4;
+    const size_t lds_ramp = ((size_t)nu_e + 2 * nu_e + 2) * 4;
     if (direct && lds_ramp > 64 * 1024)
       FDK_HIP(hipFuncSetAttribute((const void*)ramp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ramp));
     int planned_rows = 0;
@@ -419,10 +446,15 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
       }
       FDK_HIP(hipEventRecord(e0, nullptr));
       const unsigned gb = (unsigned)((elems + 255) / 256);
-      hipLaunchKernelGGL(weight_kernel, dim3(gb), dim3(256), 0, nullptr, d_raw, d_in, nu, nv, m, stride, pad_l, (float)o->du, (float)o->dv, (float)o->u0,
+      hipLaunchKernelGGL(weight_kernel, dim3(gb), dim3(256), 0, nullptr, d_raw, d_in, nu, nv, m, stride, next + pad_l, (float)o->du, (float)o->dv, (float)o->u0,
                          (float)o->v0, (float)o->sdd, d_pp + first, d_wdis + (size_t)first * nu, d_wpc, (int)wpc.size());
+      if (next > 0) {
+        const size_t ne = (size_t)m * nv * next;
+        hipLaunchKernelGGL(extend_rows_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, nullptr, d_in, stride, nu_p, next, (size_t)m * nv, d_wext);
+      }
       if (direct) {
-        hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_p, (float)scale, pad_l, pad_l + nu);
+        hipLaunchKernelGGL(ramp_rows_kernel, dim3((unsigned)(m * nv)), dim3(256), lds_ramp, nullptr, d_in, d_tmp, d_h, nu_e, (float)scale, next > 0 ? 0 : pad_l,
+                           next > 0 ? nu_e : pad_l + nu);
       } else {
         if (hipfftExecR2C(plan_fwd, d_in, (hipfftComplex*)d_spec) != HIPFFT_SUCCESS) throw FdkError{"!!ERROR!! mcgpu_fdk_reconstruct: hipfftExecR2C failed"};
         const size_t ns = (size_t)m * nv * nk;
@@ -431,14 +463,14 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
       }
       const float* filtered = d_tmp;
       if (ky.size() > 1) {
-        const size_t na = (size_t)m * nv * nu_p;
-        hipLaunchKernelGGL(smooth_cols_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, nullptr, d_tmp, d_in, nu_p, stride, nv, m, d_ky, (int)ky.size());
+        const size_t na = (size_t)m * nv * nu_e;
+        hipLaunchKernelGGL(smooth_cols_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, nullptr, d_tmp, d_in, nu_e, stride, nv, m, d_ky, (int)ky.size());
         filtered = d_in;
       }
       FDK_HIP(hipEventRecord(e1, nullptr));
       for (int b = 0; b < m; b += kBatch) {
         BackArgs A;
-        A.nx = o->nx; A.ny = o->ny; A.nz = o->nz; A.nu = nu_p; A.stride = stride; A.nv = nv; A.nb = std::min(kBatch, m - b);
+        A.nx = o->nx; A.ny = o->ny; A.nz = o->nz; A.nu = nu_p; A.u_first = next; A.stride = stride; A.nv = nv; A.nb = std::min(kBatch, m - b);
         A.x0 = (float)ox0; A.y0 = (float)oy0; A.z0 = (float)oz0; A.sx = (float)o->sx; A.sy = (float)o->sy; A.sz = (float)o->sz;
         A.sid = (float)o->sid; A.sdd = (float)o->sdd; A.inv_du = (float)(1.0 / o->du); A.inv_dv = (float)(1.0 / o->dv);
         A.u0 = (float)u0_p; A.v0 = (float)o->v0;
@@ -462,7 +494,7 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
   }
   if (plan_fwd) hipfftDestroy(plan_fwd);
   if (plan_inv) hipfftDestroy(plan_inv);
-  for (void* p : {(void*)d_spec, (void*)d_free_raw, (void*)d_in, (void*)d_tmp, (void*)d_vol, (void*)d_h, (void*)d_ky, (void*)d_wdis, (void*)d_wpc, (void*)d_pp})
+  for (void* p : {(void*)d_spec, (void*)d_free_raw, (void*)d_in, (void*)d_tmp, (void*)d_vol, (void*)d_h, (void*)d_ky, (void*)d_wdis, (void*)d_wpc, (void*)d_pp, (void*)d_free_wext})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {e0, e1, e2, e3})
     if (e) (void)hipEventDestroy(e);

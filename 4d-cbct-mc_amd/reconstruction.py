@@ -107,7 +107,7 @@ class _FdkOptions(C.Structure):
                 ("sid", C.c_double), ("sdd", C.c_double), ("gantry_deg", C.POINTER(C.c_double)), ("proj_offset_x", C.POINTER(C.c_double)),
                 ("proj_offset_y", C.POINTER(C.c_double)), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("sx", C.c_double), ("sy", C.c_double),
                 ("sz", C.c_double), ("ox", C.c_double), ("oy", C.c_double), ("oz", C.c_double), ("hann", C.c_double), ("hann_y", C.c_double),
-                ("wpc", C.POINTER(C.c_double)), ("n_wpc", C.c_int), ("device", C.c_int)]
+                ("wpc", C.POINTER(C.c_double)), ("n_wpc", C.c_int), ("device", C.c_int), ("pad", C.c_double)]
 
 
 class _FdkReport(C.Structure):
@@ -117,8 +117,9 @@ class _FdkReport(C.Structure):
 def fdk(projections: np.ndarray, geometry: CircularGeometry, pixel_spacing: Tuple[float, float], pixel_origin: Optional[Tuple[float, float]] = None,
         dimension: Tuple[int, int, int] = (464, 250, 464), spacing: Tuple[float, float, float] = (1.0, 1.0, 1.0),
         origin: Optional[Tuple[float, float, float]] = None, hann: float = 0.0, hann_y: float = 0.0,
-        water_pre_correction: Optional[Sequence[float]] = None, gpu_id: int = 0):
-    """projections [n, nv, nu] (line integrals) -> (volume [nz, ny, nx] float32 in RTK's IEC frame, report dict)."""
+        water_pre_correction: Optional[Sequence[float]] = None, gpu_id: int = 0, pad: float = 0.0):
+    """projections [n, nv, nu] (line integrals) -> (volume [nz, ny, nx] float32 in RTK's IEC frame, report dict).
+    pad: rtkfdk --pad, the truncation correction of RTK's ramp filter (0 = rows are zero-padded only)."""
     from . import engine
     lib = engine.load_library()
     lib.mcgpu_fdk_reconstruct.argtypes = [C.POINTER(_FdkOptions), C.c_void_p, C.c_void_p, C.POINTER(_FdkReport)]
@@ -138,7 +139,7 @@ def fdk(projections: np.ndarray, geometry: CircularGeometry, pixel_spacing: Tupl
                     ang.ctypes.data_as(dp), ox.ctypes.data_as(dp), oy.ctypes.data_as(dp), int(dimension[0]), int(dimension[1]), int(dimension[2]),
                     float(spacing[0]), float(spacing[1]), float(spacing[2]),
                     *(tuple(float(v) for v in origin) if origin is not None else (float("nan"),) * 3), float(hann), float(hann_y),
-                    wpc.ctypes.data_as(dp) if wpc.size else None, int(wpc.size), int(gpu_id))
+                    wpc.ctypes.data_as(dp) if wpc.size else None, int(wpc.size), int(gpu_id), float(pad))
     vol = np.zeros((int(dimension[2]), int(dimension[1]), int(dimension[0])), dtype=np.float32)
     rep = _FdkReport()
     engine._check(lib.mcgpu_fdk_reconstruct(C.byref(o), p.ctypes.data, vol.ctypes.data, C.byref(rep)))
@@ -190,13 +191,10 @@ def reconstruct_3d(projections_filepath, geometry_filepath, output_folder=None, 
     angular weights = rtk::FDKWeightProjectionFilter (angular gaps from the geometry file, as here); ramp =
     rtk::FFTRampImageFilter with `--hann` / `--hannY` windows; back-projection = rtk::FDKBackProjectionImageFilter
     (voxel-driven, bilinear); `--short 360` leaves rtk::ParkerShortScanImageFilter inactive for a full arc.
-    `--pad` (RTK: TruncationCorrection, mirror-and-feather extrapolation of truncated rows by `pad` x width before the
-    ramp) is NOT implemented: rows are zero-padded for the linear convolution only.  With the reference's default
-    pad=1.0 a truncated object (a thorax wider than the half-fan field of view) therefore shows brighter edges here
-    than in RTK; a warning says so.  Parity against RTK itself is unpinned (RTK is absent here)."""
-    if pad:
-        import warnings
-        warnings.warn("reconstruct_3d: `pad` (RTK's truncation correction) is not implemented; rows are zero-padded only", stacklevel=2)
+    `--pad` = the TruncationCorrection of rtk::FFTRampImageFilter (Ohnesorge's heuristic: rows continued by `pad` x width
+    columns with the feathered point reflection of the data before the ramp; csrc/fdk.hip: extend_rows_kernel, restated in
+    oracle/fdk_oracle.py: truncation_extension).  Parity against RTK itself is unpinned (RTK is absent here; DESIGN.md
+    section 2): the restatement is pinned by an analytic truncated cylinder (tests/test_fdk.py)."""
     projections_filepath, geometry_filepath = Path(projections_filepath), Path(geometry_filepath)
     output_folder = Path(output_folder) if output_folder else projections_filepath.parent / "reconstructions"
     output_filename = output_filename or "recon_fdk3d.mha"
@@ -204,7 +202,7 @@ def reconstruct_3d(projections_filepath, geometry_filepath, output_folder=None, 
     proj, pspacing, porigin = read_mha(projections_filepath)
     geometry = CircularGeometry.read(geometry_filepath)
     vol, report = fdk(proj, geometry, (pspacing[0], pspacing[1]), (porigin[0], porigin[1]), dimension, spacing, None, hann, hann_y,
-                      water_pre_correction, gpu_id)
+                      water_pre_correction, gpu_id, pad=pad)
     origin = tuple(-(n - 1) / 2 * s for n, s in zip(dimension, spacing))
     write_mha(output_folder / output_filename, vol, spacing, origin)
     import yaml

@@ -311,6 +311,8 @@ typedef struct mcgpu_fdk_options {
   const double *wpc;
   int n_wpc;
   int device;
+  double pad;                   /* rtkfdk --pad (truncation correction; the reference passes 1.0, reconstruction.py:29,55): rows
+                                   continued on both sides by ceil(pad x width) columns, feathered point reflection; 0 = off */
 } mcgpu_fdk_options;
 typedef struct mcgpu_fdk_report {
   double ms_filter;      /* weight + ramp + vertical smoothing kernels */

@@ -7,8 +7,11 @@ docker image, docker/compile.sh:3-18) is not in /root/reference and not installa
 published algorithm -- Feldkamp, Davis, Kress, JOSA A 1 (1984); the displaced-detector weights of Wang, Med. Phys. 29 (2002),
 which RTK applies automatically to off-centre detectors; RTK's geometry conventions as documented in its
 ThreeDCircularProjectionGeometry (Rit et al., J. Phys. Conf. Ser. 489 (2014)) -- and is pinned by analytic phantoms only
-(tests/test_fdk.py), not by RTK output.  Known differences from rtkfdk: rows are zero-padded for the linear convolution
-(no `--pad` edge extrapolation), all angular weights are 2*pi/N (uniform full scan, which is what the reference simulates).
+(tests/test_fdk.py), not by RTK output.  `--pad` (RTK: FFTRampImageFilter::TruncationCorrection, the heuristic of Ohnesorge et
+al., Med. Phys. 27 (2000)) is restated from RTK's published implementation (rtkFFTProjectionsConvolutionImageFilter.hxx,
+PadInputImageRegion): before the ramp every row is extended on both sides by next = ceil(pad x width) columns with the
+point reflection of the data about the border value, 2 p(border) - p(mirror), feathered to zero by sin^0.75 -- see
+`truncation_extension`; angular weights follow RTK's GetAngularGaps rule.
 
 Geometry (RTK): fixed IEC frame, rotation axis y.  For gantry angle t: rotated coordinates p' = Ry(-t) p =
 (x cos t - z sin t, y, x sin t + z cos t); source at p' = (0, 0, SID); detector plane z' = SID - SDD; a point projects to
@@ -86,6 +89,23 @@ def symmetric_padding(nu, du, u0, off_min, off_max):
     return pad_l, pad_r
 
 
+def truncation_extension(rows, pad):
+    """rtkfdk --pad / TruncationCorrection: rows [..., n] -> [..., n + 2 next], next = min(ceil(pad * n), n - 1) columns
+    added on each side.  Column at distance d (1..next) beyond a border holds w[d] * (2 p(border) - p(border -/+ d)) with
+    w[d] = sin((next - d) pi / (2 next - 2)) ** 0.75 (1 at the border, 0 at the far end): the row continues with its own
+    slope instead of dropping to zero, which is what makes the ramp ring at a truncated edge.  Returns (rows, next)."""
+    rows = np.asarray(rows, dtype=np.float64)
+    n = rows.shape[-1]
+    nxt = int(min(np.ceil(pad * n), n - 1)) if pad > 0 else 0
+    if nxt <= 0:
+        return rows, 0
+    d = np.arange(1, nxt + 1)
+    w = np.sin((nxt - d) * np.pi / (2.0 * nxt - 2.0)) ** 0.75 if nxt > 1 else np.zeros(1)
+    left = w * (2.0 * rows[..., :1] - rows[..., d])            # distance d left of column 0
+    right = w * (2.0 * rows[..., -1:] - rows[..., n - 1 - d])  # distance d right of column n - 1
+    return np.concatenate([left[..., ::-1], rows, right], axis=-1), nxt
+
+
 def angular_gaps(gantry_deg):
     """Angular weight of every projection [rad]: half the distance to its two neighbours on the circle (the rule of RTK's
     ThreeDCircularProjectionGeometry::GetAngularGaps, which rtkfdk's FDKWeightProjectionFilter uses); projections at the
@@ -103,8 +123,9 @@ def angular_gaps(gantry_deg):
     return np.deg2rad(gaps[inverse] / counts[inverse])
 
 
-def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, spacing, origin=None, hann=0.0, hann_y=0.0, wpc=None):
-    """proj [n][nv][nu] line integrals -> volume [nz][ny][nx] (float64).  origin = centre of voxel (0,0,0); None = centred."""
+def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, spacing, origin=None, hann=0.0, hann_y=0.0, wpc=None, pad=0.0):
+    """proj [n][nv][nu] line integrals -> volume [nz][ny][nx] (float64).  origin = centre of voxel (0,0,0); None = centred.
+    pad: rtkfdk --pad (truncation correction, see truncation_extension); 0 = rows are zero-padded only."""
     proj = np.asarray(proj, dtype=np.float64)
     n, nv, nu = proj.shape
     nx, ny, nz = dim
@@ -125,7 +146,9 @@ def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, s
     # physical edge, and the conjugate views need exactly those values.
     pad_l, pad_r = symmetric_padding(nu, du, u0, float(off_x.min()), float(off_x.max()))
     nu_p, u0_p = nu + pad_l + pad_r, u0 - pad_l * du
-    h = ramp_kernel(nu_p - 1, hann)
+    nxt = int(min(np.ceil(pad * nu_p), nu_p - 1)) if pad > 0 else 0
+    nu_e = nu_p + 2 * nxt  # row length the ramp sees
+    h = ramp_kernel(nu_e - 1, hann)
     ky = hann_y_kernel(hann_y)
     vol = np.zeros((nz, ny, nx), dtype=np.float64)
     X = origin[0] + sx * np.arange(nx)
@@ -139,8 +162,10 @@ def reconstruct(proj, du, dv, u0, v0, sid, sdd, gantry_deg, off_x, off_y, dim, s
         w_cos = sdd / np.sqrt(sdd * sdd + up[None, :] ** 2 + vp[:, None] ** 2)
         w_dis = displaced_weights(up, sdd)
         p = np.pad(proj[k] * w_cos * w_dis[None, :], ((0, 0), (pad_l, pad_r)))
-        # ramp along u (linear convolution, zero padded), scaled to the real detector: 1/du * SDD/SID
-        q = np.stack([np.convolve(row, h, mode="full")[nu_p - 1: 2 * nu_p - 1] for row in p])
+        p, _ = truncation_extension(p, pad)
+        # ramp along u (linear convolution, zero padded), scaled to the real detector: 1/du * SDD/SID; only the columns of the
+        # (symmetrically padded) detector are kept
+        q = np.stack([np.convolve(row, h, mode="full")[nu_e - 1 + nxt: nu_e - 1 + nxt + nu_p] for row in p])
         q *= (sdd / sid) / du
         if ky.size > 1:
             hk = ky.size // 2

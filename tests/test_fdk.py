@@ -96,6 +96,81 @@ def test_metaimage_round_trip(tmp_path):
     assert np.array_equal(a, v) and sp == [1.0, 2.0, 3.0] and org == [-1.0, -3.0, -6.0]
 
 
+def _truncated_sphere_case(n=120, nu=96, nv=32, du=4.0):
+    """A sphere wider than the field of view of a centred detector (radius 170 mm, FOV radius 128 mm): every row is truncated."""
+    geo = recon.create_geometry(n, start_angle=90.0, detector_offset_x=0.0)
+    u0, v0 = -(nu - 1) / 2 * du, -(nv - 1) / 2 * du
+    mu, radius = 0.02, 170.0
+    proj = fo.sphere_projections(mu, radius, (0.0, 0.0, 0.0), n, nu, nv, du, du, u0, v0, geo.source_to_isocenter, geo.source_to_detector,
+                                 np.array(geo.gantry_angles), np.array(geo.projection_offsets_x), np.array(geo.projection_offsets_y))
+    assert proj[0, nv // 2, 0] > 0.5 * proj[0, nv // 2, nu // 2]  # the rows end far above zero
+    return geo, proj, (du, du), (u0, v0), mu
+
+
+def _ring_means(vol, dim, sp, rings):
+    X = -(dim[0] - 1) / 2 * sp[0] + sp[0] * np.arange(dim[0])
+    zz, xx = np.meshgrid(X, X, indexing="ij")
+    r = np.sqrt(xx ** 2 + zz ** 2)
+    mid = vol[:, dim[1] // 2, :]
+    return [float(mid[(r >= lo) & (r < hi)].mean()) for lo, hi in rings]
+
+
+def test_truncation_extension_rule():
+    """rtkfdk --pad: point reflection about the border value, feathered by sin^0.75 (oracle header: restated from RTK's
+    published filter, parity unpinned)."""
+    rows, nxt = fo.truncation_extension(np.arange(1.0, 9.0)[None], 0.5)
+    assert nxt == 4 and rows.shape == (1, 16)
+    w = np.sin((4 - np.arange(1, 5)) * np.pi / 6.0) ** 0.75
+    assert np.allclose(rows[0, 4:12], np.arange(1.0, 9.0))
+    assert np.allclose(rows[0, 3::-1], w * (2 * 1.0 - np.arange(2.0, 6.0)))     # left of column 0: 2 p(0) - p(d)
+    assert np.allclose(rows[0, 12:], w * (2 * 8.0 - np.arange(7.0, 3.0, -1.0)))  # right of the last column
+    assert rows[0, 0] == 0 and rows[0, -1] == 0                                  # feathered to zero at the far ends
+    same, none = fo.truncation_extension(np.ones((3, 5)), 0.0)
+    assert none == 0 and same.shape == (3, 5)
+    _, capped = fo.truncation_extension(np.ones((2, 6)), 4.0)
+    assert capped == 5                                                           # never more than the row can mirror
+
+
+def test_oracle_truncation_correction_flattens_a_truncated_object():
+    """Without --pad the ramp rings at the cut-off edge of every row: the reconstruction rises towards the edge of the field
+    of view (here +26 % from the centre to the outer ring).  With the reference's --pad the profile is flat within a few
+    percent (the remaining uniform offset is the part of the object that was never measured)."""
+    geo, proj, (du, dv), (u0, v0), mu = _truncated_sphere_case()
+    dim, sp = (48, 8, 48), (5.0, 5.0, 5.0)
+    rings = ((0, 40), (80, 120))
+    flat = {}
+    for pad in (0.0, 0.5, 1.0):
+        vol = fo.reconstruct(proj, du, dv, u0, v0, geo.source_to_isocenter, geo.source_to_detector, geo.gantry_angles, geo.projection_offsets_x,
+                             geo.projection_offsets_y, dim, sp, hann=1.0, pad=pad)
+        centre, outer = _ring_means(vol, dim, sp, rings)
+        flat[pad] = outer / centre
+        assert 0.75 * mu < centre < 1.2 * mu
+    assert flat[0.0] > 1.2
+    assert abs(flat[0.5] - 1.0) < 0.08 and abs(flat[1.0] - 1.0) < 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pad,off_x,direct", [(1.0, 0.0, False), (0.5, -150.0, False), (0.3, 80.0, True)])
+def test_hip_fdk_truncation_correction_matches_the_oracle(pad, off_x, direct, monkeypatch):
+    """extend_rows_kernel + the longer ramp against the oracle's truncation_extension, centred and half-fan, both ramp routes."""
+    if direct:
+        monkeypatch.setenv("MCGPU_FDK_DIRECT_RAMP", "1")
+    if off_x == 0.0:
+        geo, proj, (du, dv), (u0, v0), mu = _truncated_sphere_case(n=90)
+    else:
+        geo, proj, (du, dv), (u0, v0), _ = _half_fan_case(n=90, off_x=off_x)
+    rng = np.random.default_rng(7)
+    proj = proj + 0.05 * rng.normal(size=proj.shape)
+    dim, sp = (48, 12, 40), (5.0, 5.0, 6.0)
+    want = fo.reconstruct(proj.astype(np.float32), du, dv, u0, v0, geo.source_to_isocenter, geo.source_to_detector, geo.gantry_angles,
+                          geo.projection_offsets_x, geo.projection_offsets_y, dim, sp, hann=1.0, hann_y=1.0, pad=pad)
+    got, _ = recon.fdk(proj, geo, (du, dv), (u0, v0), dim, sp, hann=1.0, hann_y=1.0, pad=pad)
+    plain, _ = recon.fdk(proj, geo, (du, dv), (u0, v0), dim, sp, hann=1.0, hann_y=1.0, pad=0.0)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 3e-4 * scale, np.abs(got - want).max() / scale
+    assert np.abs(got - plain).max() > 1e-2 * scale  # the correction really changes the answer
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hann,hann_y,off_x,wpc", [(0.0, 0.0, -150.0, None), (1.0, 1.0, -80.0, None), (0.7, 0.5, 0.0, (0.0, 1.05, 0.01)),
                                                  (1.0, 1.0, 150.0, None)])

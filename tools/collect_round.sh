@@ -2,7 +2,7 @@
 # End-of-round measurement set (GPU box, repo root): PMC passes first (their summaries are what the bench lines quote as
 # roofline.traffic, stamped with the kernel's source hash), then bench lines, rocprofv3 kernel stats -> gpurun_out/<tag>/
 # Usage: bash tools/collect_round.sh r02
-set -eu
+set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-r03}; OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
@@ -12,7 +12,7 @@ LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat --no-w
 bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json; cp $OUT/pmc/summary.json profiles/pmc_summary_latest.json
 for wl in thorax cirs; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
-for wl in cirs thorax; do python bench.py --workload $wl > $OUT/bench_line_$wl.json 2> $OUT/bench_line_$wl.err; done
+for wl in cirs thorax; do python bench.py --workload $wl --no-workloads > $OUT/bench_line_$wl.json 2> $OUT/bench_line_$wl.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 head -1 $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/bench_kernel_trace_track.csv; grep track_ $(find $OUT/prof -name "*kernel_trace.csv" | head -1) >> $OUT/bench_kernel_trace_track.csv
@@ -20,6 +20,6 @@ head -1 $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/bench_kerne
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ascii -- python3 tools/scan_ascii.py 24 > $OUT/scan_ascii.log 2> $OUT/scan_ascii.err
 cp $(find $OUT/prof_ascii -name "*kernel_stats.csv" | head -1) $OUT/scan_ascii_kernel_stats.csv
 python3 tools/scan_ascii.py 200 > $OUT/scan_ascii_200.log 2>&1
-BENCH_FORCE_DIST=1 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_line_forced_collective.json 2> $OUT/forced.err
+BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 8 --warmup 2 > $OUT/bench_line_2_ranks_sharing_one_gpu.json 2> $OUT/two_ranks.err
 rm -rf $OUT/prof $OUT/prof_ascii $OUT/pmc/pass* $OUT/pmc_thorax/pass* $OUT/pmc_cirs/pass*
 ls -la $OUT
