@@ -168,7 +168,8 @@ def test_hip_fdk_truncation_correction_matches_the_oracle(pad, off_x, direct, mo
     plain, _ = recon.fdk(proj, geo, (du, dv), (u0, v0), dim, sp, hann=1.0, hann_y=1.0, pad=0.0)
     scale = np.abs(want).max()
     assert np.abs(got - want).max() < 3e-4 * scale, np.abs(got - want).max() / scale
-    assert np.abs(got - plain).max() > 1e-2 * scale  # the correction really changes the answer
+    if off_x == 0.0:  # truncated rows: the correction really changes the answer (the half-fan sphere lies inside its field of view)
+        assert np.abs(got - plain).max() > 1e-2 * scale
 
 
 @pytest.mark.gpu

@@ -1,5 +1,7 @@
 """Projection post-processing and MetaImage stacks against the reference's own Python recipe
 (cbctmc/mc/projection.py:36-169) restated with numpy/scipy on the engine's ASCII files."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import scipy.ndimage as ndi
@@ -204,9 +206,13 @@ def test_scan_ascii_files_with_few_formatter_slots(engine, case_dir, tmp_path, m
 
 
 @pytest.mark.gpu
-def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_path):
-    """mcgpu_run_scan_multi: three contexts (here on one device) shard the histories, the first one's device reduces the
-    tallies peer to peer, finalizes and writes; stacks and ASCII files equal the single-context scan bit for bit."""
+@pytest.mark.parametrize("policy", ["1", "0"])
+def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_path, monkeypatch, policy):
+    """mcgpu_run_scan_multi: three contexts (here on one device) shard the histories; every projection's tallies are summed on
+    its owner through the tally exchange (exchange.cpp: copy-engine pushes, one fused add), finalized and written there -- the
+    owner rotates over the devices (policy 1) or is always the first one (policy 0, the reference's root).  Stacks and ASCII
+    files equal the single-context scan bit for bit."""
+    monkeypatch.setenv("MCGPU_EXCHANGE_POLICY", policy)
     n_hist = 500_000
     outs = []
     for k, n_peers in enumerate((0, 2)):
@@ -214,14 +220,17 @@ def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_
         out.mkdir()
         ctxs = [engine.create(case_dir("catphan64_ct"), device=0) for _ in range(1 + n_peers)]
         try:
-            rep = ctxs[0].run_scan(mode="fast", histories=n_hist, crop_nx=128, write_ascii=False, output_folder=out, peers=ctxs[1:])
+            rep = ctxs[0].run_scan(mode="fast", histories=n_hist, crop_nx=128, write_ascii=True, output_folder=out, peers=ctxs[1:])
             assert rep["projections"] == 4 and rep["histories_per_projection"] == n_hist
+            ascii_files = [Path(ctxs[0].projection_file_name(p)).read_bytes() for p in range(4)]
         finally:
             for c in ctxs:
                 c.close()
         outs.append({m: engine.stack_read(out / f"projections_{m}.mha") for m in ("total", "unscattered", "scattered")})
-    for m in outs[0]:
+        outs[-1]["ascii"] = [[l for l in t.split(b"\n") if not l.startswith(b"#")] for t in ascii_files]  # data lines (the footer times differ)
+    for m in ("total", "unscattered", "scattered"):
         assert np.array_equal(outs[0][m], outs[1][m]), m
+    assert outs[0]["ascii"] == outs[1]["ascii"] and len(outs[0]["ascii"][0]) > 1000
     # COMPAT mode shards RANECU batches: same statement
     res = []
     for n_peers in (0, 1):
