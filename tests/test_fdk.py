@@ -229,7 +229,9 @@ def test_reconstruct_3d_file_flow(tmp_path):
     vol, vsp, vorg = recon.read_mha(out)
     assert vol.shape == (64, 40, 64) and vsp == [4.0, 4.0, 4.0] and vorg == [-126.0, -78.0, -126.0]
     inside, outside = _sphere_masks(dim, sp, centre, radius, 16.0)
-    assert abs(vol[inside].mean() / mu - 1.0) < 0.01 and abs(vol[outside].mean()) < 0.03 * mu
+    # the reference's default pad = 1.0 is in force: the rows of this sphere end at zero, so nothing is extended, but the
+    # Hann-apodised ramp is cut off three times further out than without padding (1.2 % instead of 0.9 % here)
+    assert abs(vol[inside].mean() / mu - 1.0) < 0.015 and abs(vol[outside].mean()) < 0.03 * mu
 
 
 @pytest.mark.gpu
