@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -115,6 +116,16 @@ struct mcgpu_exchange {
 
 namespace {
 
+// how long a rank waits for a peer's counter before it gives up with an error (MCGPU_EXCHANGE_TIMEOUT_S, default 120)
+double wait_limit_seconds() {
+  static const double limit = [] {
+    const char* v = getenv("MCGPU_EXCHANGE_TIMEOUT_S");
+    const double s = v ? atof(v) : 120.0;
+    return s > 0.0 ? s : 120.0;
+  }();
+  return limit;
+}
+
 void spin_until(mcgpu_exchange* x, const std::atomic<long long>& counter, long long at_least, int peer, const char* what) {
   if (counter.load(std::memory_order_acquire) >= at_least) return;
   const auto t0 = std::chrono::steady_clock::now();
@@ -123,8 +134,9 @@ void spin_until(mcgpu_exchange* x, const std::atomic<long long>& counter, long l
     if (x->boxes[peer].closing.load(std::memory_order_acquire) != 0)
       throw XError{-4, std::string("!!ERROR!! tally exchange: rank ") + std::to_string(peer) + " left while rank " + std::to_string(x->rank) + " waited for its " + what};
     if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
-    if ((spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
-      throw XError{-4, std::string("!!ERROR!! tally exchange: rank ") + std::to_string(x->rank) + " waited 120 s for the " + what + " of rank " + std::to_string(peer)};
+    if ((spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_seconds())
+      throw XError{-4, std::string("!!ERROR!! tally exchange: rank ") + std::to_string(x->rank) + " gave up waiting for the " + what + " of rank " + std::to_string(peer) +
+                           " (MCGPU_EXCHANGE_TIMEOUT_S)"};
   }
   x->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -99,3 +99,42 @@ def test_exchange_between_two_processes_on_one_gpu(engine, case_dir, tmp_path, p
             alone, _, _ = ctx.run_projection(k % nproj, world * hist, mode="fast", seed=seed, first=0)
             got = np.load(tmp_path / f"reduced_{k}.npy")
             assert np.array_equal(got, alone) and alone.sum() > 0, k
+
+
+@pytest.mark.gpu
+def test_exchange_gives_up_on_a_silent_peer_instead_of_hanging(engine, case_dir, tmp_path):
+    """An owner whose peer never pushes gets an error return after MCGPU_EXCHANGE_TIMEOUT_S (default 120 s), and so does a
+    rank whose peer has been destroyed -- the host side of the protocol never blocks forever, and nothing is left waiting on
+    the device."""
+    code = f"""
+import sys, time
+sys.path.insert(0, {str(HERE)!r})
+import cases
+eng = cases.pkg.engine
+ctx = eng.create({str(case_dir("catphan64_ct"))!r}, device=0)
+shared = bytearray(eng.Exchange.shared_bytes(2))
+xs = [eng.Exchange(0, r, 2, ctx.image_words, shared, eng.EXCHANGE_ROOT0 | eng.EXCHANGE_LOCAL) for r in range(2)]
+xs[0].connect_local(xs[1]); xs[1].connect_local(xs[0])
+t = xs[0].begin(0); ctx.launch(0, t, 100000, mode="fast", seed=1); xs[0].submit(0)
+t0 = time.time()
+try:
+    xs[0].collect(0)          # rank 1 never submitted step 0
+    print("NO ERROR")
+except eng.EngineError as e:
+    print("ERROR after %.1f s: %s" % (time.time() - t0, e.message))
+xs[1].close()                 # ... and a peer that has gone is noticed at once
+t = xs[0].begin(1); ctx.launch(0, t, 100000, mode="fast", seed=1); xs[0].submit(1)
+t0 = time.time()
+try:
+    xs[0].collect(1)
+    print("NO ERROR")
+except eng.EngineError as e:
+    print("ERROR after %.1f s: %s" % (time.time() - t0, e.message))
+xs[0].close(); ctx.close()
+print("CLEAN EXIT")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MCGPU_EXCHANGE_TIMEOUT_S="2"), capture_output=True, text=True, timeout=120)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("ERROR", "NO ERROR", "CLEAN"))]
+    assert r.returncode == 0 and len(lines) == 3 and lines[2] == "CLEAN EXIT", (r.stdout, r.stderr)
+    assert lines[0].startswith("ERROR after 2.") and "gave up waiting for the push of rank 1" in lines[0]
+    assert lines[1].startswith("ERROR after 0.") and "rank 1 left" in lines[1]
