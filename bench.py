@@ -319,22 +319,36 @@ def spawn_ranks(n: int) -> int:
     env0.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": env0.get("MASTER_PORT", str(free_port())),
                  "BENCH_SPAWNED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": env0.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     procs = []
+    line_file = tempfile.TemporaryFile()  # rank 0's stdout: the one JSON line
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
-    line = procs[0].stdout.read()  # rank 0 prints the one line at its very end
+                                      stdout=line_file if r == 0 else sys.stderr.fileno()))
+    # wait for all of them; the first rank that fails ends the run (its peers would otherwise sit in a collective until the
+    # process group's own timeout)
+    deadline = time.time() + float(os.environ.get("BENCH_RANK_TIMEOUT_S", "900"))
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        failed_now = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if failed_now or time.time() > deadline:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()  # exactly the processes started here
+                    codes[r] = p.wait()
+                    if not failed_now:
+                        print(f"bench.py: rank {r} did not finish in time", file=sys.stderr)
+            break
+        time.sleep(0.05)
     rc = 0
-    deadline = time.time() + 600.0
-    for r, p in enumerate(procs):
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # exactly the process started here
-            code = -9
+    for r, code in enumerate(codes):
         if code != 0:
             print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
-            rc = rc or (code if code > 0 else 1)
+            rc = rc or (code if code and code > 0 else 1)
+    line_file.seek(0)
+    line = line_file.read()
     if rc == 0 and not line.strip():
         print("bench.py: rank 0 printed no result line", file=sys.stderr)
         rc = 1
@@ -474,23 +488,34 @@ def main():
             last_reduced[0] = got or last_reduced[0]
             collected[0] += 1
 
+    kernel_events = []     # (start, stop) HIP events around every timed launch, on the stream it is launched on; read after the region
+
     def step(i, timed, hist=H, projection=None):
         p = (i * 149) % nproj if projection is None else projection  # spread the sampled projections over the arc
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
         if x:
             k = n_step[0]
             tally = x.begin(k, stream)
+            if ev:
+                ev[0].record()
             ctx.launch(p, tally, hist, mode="fast", seed=seed, first=rank * hist, stream=stream)  # disjoint history ids per rank
+            if ev:
+                ev[1].record()
             x.submit(k, stream)
             collect_up_to(k)  # step k - 1, behind this kernel: its pushes had the whole kernel to land
             n_step[0] = k + 1
         else:
             image = images[filled[0]]
             ctx.clear(image.data_ptr(), stream)
+            if ev:
+                ev[0].record()
             ctx.launch(p, image.data_ptr(), hist, mode="fast", seed=seed, first=rank * hist, stream=stream)
+            if ev:
+                ev[1].record()
             filled[0] += 1
             last_reduced[0] = image
-        if timed:
-            kernel_ms.append(ctx.last_kernel_ms())  # waits for this launch only
+        if ev:
+            kernel_events.append(ev)  # no host wait inside the timed region: the stream never runs dry between two projections
         if not x and filled[0] == G:
             reduce_group()
 
@@ -516,6 +541,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kernel_ms.extend(a.elapsed_time(b) for a, b in kernel_events)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

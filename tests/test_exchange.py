@@ -25,11 +25,14 @@ def test_exchange_sizes_and_argument_checks(engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,policy", [(3, "rotate"), (2, "rank0"), (1, "rotate")])
-def test_exchange_between_contexts_of_one_process(engine, case_dir, world, policy):
-    inp = case_dir("catphan64_ct")
+@pytest.mark.parametrize("world,policy,hist", [(3, "rotate", 150_000), (2, "rank0", 150_000), (1, "rotate", 150_000), (3, "rotate", 1500), (2, "rank0", 1500)])
+def test_exchange_between_contexts_of_one_process(engine, case_dir, world, policy, hist):
+    """hist = 1500: kernels of a few microseconds against pushes of 0.75 ms (full-size detector), so the owner's fused add is
+    enqueued while the push it needs is still in flight: the events, not luck, must order them."""
+    # the stress cases use the reference's full detector: 45 MB tallies, pushes of 0.75 ms against kernels of a few microseconds
+    inp = case_dir("catphan64_ct") if hist > 10_000 else case_dir("catphan64_ct", n_detector_pixels=(1848, 768), detector_size=(717.024, 297.984))
     pol = (engine.EXCHANGE_ROTATE if policy == "rotate" else engine.EXCHANGE_ROOT0) | engine.EXCHANGE_LOCAL
-    steps, hist = 9, 150_000
+    steps = 9 if hist > 10_000 else 24
     shared = bytearray(engine.Exchange.shared_bytes(world))
     ctxs = [engine.create(inp, device=0) for _ in range(world)]
     xs = []
@@ -71,11 +74,13 @@ def test_exchange_between_contexts_of_one_process(engine, case_dir, world, polic
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", [1, 0])
-def test_exchange_between_two_processes_on_one_gpu(engine, case_dir, tmp_path, policy):
-    """IPC memory handles + interprocess events: two rank processes (fresh interpreters) share the box's GPU."""
-    inp = case_dir("catphan64_ct")
-    world, steps, hist = 2, 7, 200_000
+@pytest.mark.parametrize("policy,steps,hist", [(1, 7, 200_000), (0, 7, 200_000), (1, 30, 1000)])
+def test_exchange_between_two_processes_on_one_gpu(engine, case_dir, tmp_path, policy, steps, hist):
+    """IPC memory handles + interprocess events: two rank processes (fresh interpreters) share the box's GPU.  The last case
+    runs 30 steps of tiny kernels on the full-size detector: the 45 MB pushes take much longer than the kernels, so every add
+    really waits on its interprocess event."""
+    inp = case_dir("catphan64_ct") if hist > 10_000 else case_dir("catphan64_ct", n_detector_pixels=(1848, 768), detector_size=(717.024, 297.984))
+    world = 2
     shm = Path("/dev/shm") / f"mcgpu_exchange_test_{os.getpid()}_{policy}"
     engine.Exchange.open_shared(shm, world, create=True).close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
