@@ -62,7 +62,10 @@ struct DeviceLane {  // per device
   hipStream_t stream = nullptr;
   mcgpu_exchange* x = nullptr;                 // this device's end of the tally exchange (owns the tally buffers)
   void* planes_dev[2] = {nullptr, nullptr};    // float32 planes of the projections this device owns
-  hipEvent_t done[2] = {nullptr, nullptr};     // planes of pinned buffer b are on the host (system-scope release)
+  hipStream_t copy = nullptr;                  // their download: a copy engine, beside the next tracking kernel
+  hipEvent_t finalized[2] = {nullptr, nullptr};  // planes_dev[b] has been written (tracking stream)
+  hipEvent_t done[2] = {nullptr, nullptr};     // planes of pinned buffer b are on the host (system-scope release; copy stream)
+  bool done_valid[2] = {false, false};
   unsigned long long lo = 0, hi = 0;           // shard of the units of every projection
 };
 
@@ -236,7 +239,9 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     for (int g = 0; g < n_ctx; ++g) {  // every device that can own a projection finalizes it
       if (g > 0 && !(policy & MCGPU_EXCHANGE_ROTATE)) break;
       HIP_OK(hipSetDevice(D[g].dev));
+      HIP_OK(hipStreamCreateWithFlags(&D[g].copy, hipStreamNonBlocking));
       for (int b = 0; b < 2; ++b) {
+        HIP_OK(hipEventCreateWithFlags(&D[g].finalized[b], hipEventDisableTiming));
         HIP_OK(hipMalloc(&D[g].planes_dev[b], 3 * plane * 4));
         // the writer thread reads non-coherent pinned memory after waiting on this event: that needs a SYSTEM-scope release,
         // which a default event does not promise (device scope only)
@@ -367,9 +372,16 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
         if (ascii_on_host) HIP_OK(hipMemcpyAsync(image_host[b], tally, words * 8, hipMemcpyDeviceToHost, so));
         else ABI_OK(mcgpu_format_projection(D[o].ctx, tally, total, j % n_ascii, so));
       }
+      // planes_dev[b] was last downloaded two projections ago (by this device, if it owned that one)
+      if (D[o].done_valid[b]) HIP_OK(hipStreamWaitEvent(so, D[o].done[b], 0));
       ABI_OK(mcgpu_finalize_projection(D[o].ctx, tally, total, cx, D[o].planes_dev[b], 0, so));  // begin() zeroes the buffer for its next user
-      HIP_OK(hipMemcpyAsync(planes_host[b], D[o].planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, so));
-      HIP_OK(hipEventRecord(D[o].done[b], so));
+      // the 9 MB of planes go to the host on a copy engine, beside the next tracking kernel (on the tracking stream the copy
+      // held the next launch back by 0.17 ms per projection)
+      HIP_OK(hipEventRecord(D[o].finalized[b], so));
+      HIP_OK(hipStreamWaitEvent(D[o].copy, D[o].finalized[b], 0));
+      HIP_OK(hipMemcpyAsync(planes_host[b], D[o].planes_dev[b], 3 * plane * 4, hipMemcpyDeviceToHost, D[o].copy));
+      HIP_OK(hipEventRecord(D[o].done[b], D[o].copy));
+      D[o].done_valid[b] = true;
     };
     auto publish = [&](int j) {  // kms[j] is final: the writer may take projection j
       std::lock_guard<std::mutex> lk(sh.mu);
@@ -481,6 +493,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     if (d.dev < 0) continue;
     (void)hipSetDevice(d.dev);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.copy) (void)hipStreamSynchronize(d.copy);
   }
   if (D[0].dev >= 0) {
     (void)hipSetDevice(D[0].dev);
@@ -496,7 +509,9 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     for (int b = 0; b < 2; ++b) {
       if (d.planes_dev[b]) (void)hipFree(d.planes_dev[b]);
       if (d.done[b]) (void)hipEventDestroy(d.done[b]);
+      if (d.finalized[b]) (void)hipEventDestroy(d.finalized[b]);
     }
+    if (d.copy) (void)hipStreamDestroy(d.copy);
   }
   for (auto& d : D)  // after every device has drained: an exchange end frees memory its peers push into
     if (d.x) mcgpu_exchange_destroy(d.x);
