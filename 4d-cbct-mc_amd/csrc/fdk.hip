@@ -375,8 +375,19 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     // Ramp filter: FFT (hipFFT, rows zero-extended to L >= 2 nu_p - 1: no wrap-around inside the nu_p columns that are used) or,
     // with MCGPU_FDK_DIRECT_RAMP, the direct LDS convolution (same result up to float rounding; tests compare both to the oracle)
     const bool direct = getenv("MCGPU_FDK_DIRECT_RAMP") != nullptr;
-    int L = 1;
-    while (L < 2 * nu_e - 1) L *= 2;
+    // The ramp is a linear convolution evaluated as a circular one of length L.  Only the nu_p detector columns in the middle of
+    // a row are ever read, and for those the lag between an output and any of the nu_e data columns is at most M = nu_p + next - 1:
+    // with the kernel cut to |lag| <= M, L >= 2 M + 1 keeps every lag distinct (and L >= nu_e holds the row).  L = the smallest
+    // even 2^a 3^b 5^c at or above that -- 7680 instead of 16384 for the reference's half-fan rows with pad = 1.
+    const int max_lag = nu_p + next - 1;
+    int L = std::max(2 * max_lag + 1, nu_e);
+    for (;; ++L) {
+      if (L & 1) continue;
+      int m = L;
+      for (int f : {2, 3, 5})
+        while (m % f == 0) m /= f;
+      if (m == 1) break;
+    }
     const int stride = direct ? nu_e : L;        // floats per detector row in the filtered buffers
     const int nk = L / 2 + 1;
     const size_t plane_p = (size_t)stride * nv;
@@ -405,11 +416,22 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* pr
     } else {
       // spectrum of the kernel laid out circularly (lag n at index n mod L); real because the kernel is even;
       // the scale of the filter and hipFFT's missing 1/L are folded in
-      std::vector<std::complex<double>> c((size_t)L, 0.0);
-      for (int lag = -(nu_e - 1); lag <= nu_e - 1; ++lag) c[(size_t)((lag + L) % L)] = hd[(size_t)(lag + nu_e - 1)];
-      fft(c, false);
+      // L is not a power of two: the (real, even) kernel's spectrum by its cosine sum, H[k] = h[0] + 2 sum_lag h[lag] cos(2 pi k lag / L),
+      // with one table of cosines (30 M multiply-adds in double: tens of milliseconds, once per reconstruction)
+      std::vector<double> cosine((size_t)L);
+      for (int t = 0; t < L; ++t) cosine[(size_t)t] = std::cos(2.0 * M_PI * (double)t / (double)L);
       std::vector<float> H((size_t)nk);
-      for (int k = 0; k < nk; ++k) H[(size_t)k] = (float)(c[(size_t)k].real() * scale / (double)L);
+      const double* h0 = hd.data() + (nu_e - 1);  // h0[lag], lag = -(nu_e - 1) .. nu_e - 1
+      for (int k = 0; k < nk; ++k) {
+        double acc = h0[0];
+        size_t t = 0;  // (k * lag) mod L
+        for (int lag = 1; lag <= max_lag; ++lag) {
+          t += (size_t)k;
+          if (t >= (size_t)L) t -= (size_t)L;
+          acc += 2.0 * h0[lag] * cosine[t];
+        }
+        H[(size_t)k] = (float)(acc * scale / (double)L);
+      }
       FDK_HIP(hipMalloc(&d_h, H.size() * 4));
       FDK_HIP(hipMemcpy(d_h, H.data(), H.size() * 4, hipMemcpyHostToDevice));
       FDK_HIP(hipMalloc(&d_spec, (size_t)chunk * nv * nk * sizeof(float2)));

@@ -16,13 +16,14 @@ proj = fo.sphere_projections(mu, radius, centre, n, nu, nv, du, du, u0, v0, geo.
                              np.array(geo.gantry_angles), np.array(geo.projection_offsets_x), np.array(geo.projection_offsets_y)).astype(np.float32)
 print(f"analytic projections: {time.time() - t0:.1f} s", flush=True)
 dim, sp = (464, 250, 464), (1.0, 1.0, 1.0)
-for rep in range(2):
-    t0 = time.time()
-    vol, r = recon.fdk(proj, geo, (du, du), (u0, v0), dim, sp, hann=1.0, hann_y=1.0)
-    wall = time.time() - t0
 updates = n * dim[0] * dim[1] * dim[2]
-print(f"filter {r['ms_filter']:.1f} ms, backprojection {r['ms_backproject']:.1f} ms ({updates / r['ms_backproject'] / 1e6:.1f} G voxel updates/s), "
-      f"wall incl. PCIe both ways {wall:.2f} s")
+for pad in (0.0, 1.0):  # 1.0 = the reference's default truncation correction: rows three times as long through the ramp
+    for rep in range(2):
+        t0 = time.time()
+        vol, r = recon.fdk(proj, geo, (du, du), (u0, v0), dim, sp, hann=1.0, hann_y=1.0, pad=pad)
+        wall = time.time() - t0
+    print(f"pad {pad}: filter {r['ms_filter']:.1f} ms, backprojection {r['ms_backproject']:.1f} ms ({updates / r['ms_backproject'] / 1e6:.1f} G voxel updates/s), "
+          f"wall incl. PCIe both ways {wall:.2f} s")
 X, Y, Z = [-(k - 1) / 2 * s + s * np.arange(k) for k, s in zip(dim, sp)]
 zz, yy, xx = np.meshgrid(Z, Y, X, indexing="ij")
 rr = np.sqrt((xx - centre[0]) ** 2 + (yy - centre[1]) ** 2 + (zz - centre[2]) ** 2)
