@@ -208,10 +208,12 @@ typedef struct mcgpu_scan_report {
 } mcgpu_scan_report;
 int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
 /* The same over several devices of one node (contexts created from the same input file, one per device): every
- * projection's histories are sharded over the contexts (the reference's `mpirun -n N`, MC-GPU_v1.3.cu:728-731,823-841), the
- * per-device tallies are copied to the first context's device peer-to-peer and added there (the MPI_Reduce of :1019), then
- * finalized and written as above.  Tally buffers are double-buffered per device: no device waits for the reduce.  Dose
- * tallies stay per context (sum them with mcgpu_dose_read). */
+ * projection's histories are sharded over the contexts (the reference's `mpirun -n N`, MC-GPU_v1.3.cu:728-731,823-841) and the
+ * per-device tallies are summed through the tally exchange below (the MPI_Reduce of :1019): every projection has an owner
+ * device (projection mod devices; MCGPU_EXCHANGE_POLICY=0: always the first), the others push their tally to it with a copy
+ * engine beside their next kernel, the owner adds them in one pass, finalizes, formats and downloads the projection; the
+ * writer thread takes the results in projection order.  No device waits for the sum.  Dose tallies stay per context (sum
+ * them with mcgpu_dose_read). */
 int mcgpu_run_scan_multi(mcgpu_ctx *const *ctxs, int n_ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
 
 /* ---- The tally exchange between the GPUs of one node: the sum of the per-rank detector tallies that the reference does with
