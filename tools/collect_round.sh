@@ -13,7 +13,7 @@ bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $O
 for wl in thorax cirs; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 for wl in cirs thorax; do python bench.py --workload $wl --no-workloads > $OUT/bench_line_$wl.json 2> $OUT/bench_line_$wl.err; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 head -1 $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/bench_kernel_trace_track.csv; grep track_ $(find $OUT/prof -name "*kernel_trace.csv" | head -1) >> $OUT/bench_kernel_trace_track.csv
 # the drop-in default: ASCII projection files formatted on the device (kernel stats of a 24-projection scan)
