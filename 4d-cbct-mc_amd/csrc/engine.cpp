@@ -430,7 +430,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       // Round 2 (x-fastest rows): worth its dependent L2 round trip where most bricks a photon meets are mixed (thorax +24 %).
       // Round 3: the volume is stored in 4x4x4 TILES, one tile = one 64-byte sector = one sub-brick -- asking the volume
       // directly now costs one sector like asking this table, without the second dependent round trip, and the tile it
-      // brings in serves the neighbouring voxels of later photons.  Measured on one box (tools/batch_e.sh): thorax 14.27
+      // brings in serves the neighbouring voxels of later photons.  Measured on one box (tools/ab_second_level.sh): thorax 14.27
       // -> 13.68 ms, CIRS 6.52 -> 6.25, Catphan 4.17 -> 4.09 with the table OFF.  So it is off unless MCGPU_SUB_BRICKS=1
       // asks for it (kept: it halves the fabric traffic where that is what binds, and the tests hold both routes to the
       // same tallies).

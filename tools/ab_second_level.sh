@@ -1,3 +1,5 @@
+# A/B on one GPU box: every engine build under build/ab/*.so on the three bench workloads (tools/ab.sh), then the second brick
+# level on / off (MCGPU_SUB_BRICKS) with the default library.  Usage: bash tools/ab_second_level.sh
 mkdir -p gpurun_out/r03e
 bash tools/ab.sh > gpurun_out/r03e/ab.txt 2>&1
 B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads"
