@@ -273,3 +273,21 @@ def test_clone_shares_the_parsed_model(engine, case_dir):
     assert twin.num_projections == nproj == 3 and twin.geti("seed") == seed
     assert twin.projection_file_name(1).endswith("projection_300.500000deg")
     twin.close()
+
+
+def test_committed_pmc_summaries_belong_to_this_kernel_build():
+    """bench.py quotes `roofline.traffic` from the committed rocprofv3 PMC summaries and refuses one that was collected from
+    another build of the FAST kernel (source hash) or another workload.  A kernel change without a fresh collection
+    (tools/collect_round.sh) would silently turn the driver's `traffic` into null: caught here instead."""
+    import json
+    import bench
+    for workload, name in (("catphan", "pmc_summary_latest.json"), ("cirs", "pmc_summary_cirs.json"), ("thorax", "pmc_summary_thorax.json")):
+        stamp = json.loads((ROOT / "profiles" / name).read_text())["_stamp"]
+        assert stamp["workload"] == workload, name
+        assert stamp["kernel_source_sha16"] == bench.kernel_source_hash(), f"{name} is of another kernel build: run tools/collect_round.sh on a GPU box"
+        d, src = bench.pmc_summary(workload)
+        assert d is not None and name in src
+    roof, valu = bench.roofline_block("catphan", int(1e8), 4.0)
+    assert roof["traffic"] > 1e9 and 0 < roof["frac"] < 1 and roof["bound"] == "hbm" and 0.3 < valu["lane_utilisation"] < 1
+    roof, _ = bench.roofline_block("catphan", int(5e7), 2.0)  # the summaries are per 1e8-history launch
+    assert roof["traffic"] is None and roof["frac"] > 0
