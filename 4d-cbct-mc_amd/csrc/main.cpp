@@ -5,7 +5,8 @@
 // is only ever printed on failure (simulation.py:204 greps for it).  Options after the input file:
 //   --mode fast|compat   kernel personality (default fast)
 //   --gpus N             history-shard every projection over devices 0..N-1 of this node (default 1: the input file's
-//                        GPU number); the per-device tallies are added on the first device (integers: order-independent)
+//                        GPU number); the per-device tallies are summed through the tally exchange (exchange.cpp: copy-engine
+//                        pushes to the projection's owner device, one fused add; integers: order-independent)
 //   --devices a,b,...    the same with an explicit device list (a device may appear twice: used by the tests to run the
 //                        sharded path on a single-GPU box)
 //   --no-output          skip the ASCII projection files (timing runs, or stacks only)

@@ -146,6 +146,33 @@ def test_executable_sharded_over_devices_equals_single_device(engine, tmp_path):
         assert s1.shape == (4, 96, 128) and np.array_equal(s1, s2), m
 
 
+def test_reference_command_line_through_the_mpirun_shim(engine, tmp_path):
+    """What `MCSimulation.run_simulation` executes inside the container (cbctmc/mc/simulation.py:187-198): `mpirun --tag-output
+    -v -n <gpus> MC-GPU_v1.3.x <input>`, its stdout scanned for progress lines and for the word "error", its projection files
+    parsed afterwards.  Here the shim of the ROCm image (docker/mpirun) runs the real executable on the box's GPU; the files
+    equal those of the executable called directly."""
+    from pathlib import Path
+    shim = Path(cases.ROOT) / "docker" / "mpirun"
+    a = cases.build_case("catphan64_ct", tmp_path / "shim", n_histories=300_000)
+    b = cases.build_case("catphan64_ct", tmp_path / "direct", n_histories=300_000)
+    r1 = subprocess.run(["sh", str(shim), "--tag-output", "-v", "-n", "1", str(engine.EXE_PATH), str(a)], capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([str(engine.EXE_PATH), str(b)], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    assert not re.search("(?i)error", r1.stdout)
+    found = re.findall(r"Simulating Projection (\d{1,4}) of (\d{1,4})", r1.stdout)
+    assert [int(i) for i, _ in found] == [1, 2, 3, 4]
+    names = sorted(f.name for f in (tmp_path / "shim").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
+    assert len(names) == 4
+    data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]
+    for n in names:
+        assert data(tmp_path / "shim" / n) == data(tmp_path / "direct" / n), n
+        assert _read_like_reference(tmp_path / "shim" / n, 96, 231).sum() > 0
+    # more ranks than the box has GPUs: the reference's mpirun would fail to bind its ranks; the shim's executable says so and
+    # the caller's scan for "error" catches it
+    r3 = subprocess.run(["sh", str(shim), "-n", "3", str(engine.EXE_PATH), str(a)], capture_output=True, text=True, timeout=600)
+    assert r3.returncode != 0 and re.search("(?i)error", r3.stdout)
+
+
 def test_executable_time_limited_run(engine, tmp_path):
     """An input "number of histories" below 95000 is a time budget in seconds per projection (MC-GPU_v1.3.cu:650-655)."""
     inp = cases.build_case("water", tmp_path, n_histories=1)
