@@ -88,17 +88,34 @@ def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "sca
     return send.numel() * send.element_size() + part_w.numel() * part_w.element_size()
 
 
-def connect_exchange(x, dist) -> None:
+def connect_exchange(x, dist):
     """Swap the address cards of a tally exchange (engine.Exchange: IPC memory and event handles of every rank's landing
     buffer) between the ranks of the initialised process group `dist` (torch.distributed, any backend) and connect this
-    rank's end to every peer.  Collective: every rank calls it once."""
+    rank's end to every peer.  Collective: every rank calls it once, with `x = None` if it could not even create its end.
+    Returns (ok, error): ok is the SAME on every rank -- False if any rank failed anywhere (no IPC between these devices, an
+    interprocess event refused ...), so that all ranks take the same fallback; it never leaves a peer waiting in a collective."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    err = None
+    card = None
+    if x is not None:
+        try:
+            card = x.card()
+        except Exception as e:  # noqa: BLE001 -- reported, and agreed on below
+            err = e
     cards = [None] * world
-    dist.all_gather_object(cards, x.card())
-    for peer in range(world):
-        if peer != rank:
-            x.connect(peer, cards[peer])
-    dist.barrier()  # nobody starts pushing before everybody has mapped everybody
+    dist.all_gather_object(cards, card)
+    if x is None or any(c is None for c in cards):
+        err = err or RuntimeError("a rank has no exchange end")
+    else:
+        try:
+            for peer in range(world):
+                if peer != rank:
+                    x.connect(peer, cards[peer])
+        except Exception as e:  # noqa: BLE001
+            err = e
+    flags = [None] * world
+    dist.all_gather_object(flags, err is None)  # also the barrier: nobody starts pushing before everybody has mapped everybody
+    return all(flags), err
 
 
 _BUFFERS: dict = {}

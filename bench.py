@@ -461,10 +461,24 @@ def main():
         barrier()
         if rank != 0:
             shared_map = eng.Exchange.open_shared(shm, world, create=False)
-        x = eng.Exchange(device, rank, world, ctx.image_words, shared_map, policy)
-        cases.pkg.sharding.connect_exchange(x, dist)
+        try:
+            x = eng.Exchange(device, rank, world, ctx.image_words, shared_map, policy)
+            why = None
+        except eng.EngineError as e:
+            x, why = None, e
+        ok, err = cases.pkg.sharding.connect_exchange(x, dist)  # the same verdict on every rank
         if rank == 0:
             shm.unlink(missing_ok=True)  # every rank holds its mapping
+        if not ok:
+            # no IPC between these ranks' devices (or the runtime refused an interprocess event): every rank falls back to the
+            # RCCL reduction together -- slower (the collective is exposed between kernels), but a measurement instead of a failure
+            print(f"bench.py: rank {rank}: the tally exchange is not available here ({why or err}); falling back to BENCH_EXCHANGE=rccl", file=sys.stderr)
+            if x:
+                x.close()
+            x = None
+            if backend == "gloo":
+                raise SystemExit("bench.py: ranks that share a GPU have no RCCL to fall back to")
+            exchange_kind = "rccl"
     G = max(1, int(os.environ.get("BENCH_REDUCE_GROUP", "8"))) if exchange_kind == "rccl" else 1
     images = None if x else torch.zeros((G, 4, nz, nx), dtype=torch.int64, device="cuda")
     filled = [0]

@@ -123,8 +123,12 @@ def _handshake_worker(rank, world, port, shm_path, out_dir):
         m = eng.Exchange.open_shared(shm_path, world, create=False)
     assert len(m) == eng.Exchange.shared_bytes(world) and bytes(m[:]) == b"\0" * len(m)
     fx = _FakeExchange(rank, world)
-    cases.pkg.sharding.connect_exchange(fx, dist)
+    ok, err = cases.pkg.sharding.connect_exchange(fx, dist)
+    assert ok and err is None
     assert sorted(fx.connected) == [r for r in range(world) if r != rank]
+    # a rank without an exchange end (its device refused IPC, say): EVERY rank learns it, nobody is left in a collective
+    ok, err = cases.pkg.sharding.connect_exchange(None if rank == 1 else _FakeExchange(rank, world), dist)
+    assert not ok and err is not None
     assert all(card == bytes([peer]) * 64 * (3 + 2 * world) for peer, card in fx.connected.items())
     # one mapping for everybody: a counter written by one rank is seen by the other
     m[64 + 8 * rank] = 7 + rank
