@@ -105,7 +105,7 @@ struct DeviceModel {
   // mcgpu_reload_env_knobs: the launch path itself never looks at the environment and never synchronises.
   struct Knobs {
     int exterior_mode = 3;                           // MCGPU_EXTERIOR_MODE: bit 0 hop during flight, bit 1 hop at the source
-    int compat_thresh[3] = {20, 6, 24};              // MCGPU_COMPAT_THRESH_{COMPTON,RAYLEIGH,NEW}
+    int compat_thresh[3] = {-1, -1, -1};             // MCGPU_COMPAT_THRESH_{COMPTON,RAYLEIGH,NEW}; -1: chosen from the materials (make_args)
     int blocks_per_cu = 0;                           // MCGPU_BLOCKS_PER_CU (0: ask the occupancy API)
     int grid_spare_percent = 0;                      // MCGPU_GRID_SPARE_PERCENT
     int sched_override[5] = {-1, -1, -1, -1, -1};    // MCGPU_THRESH_{COMPTON,RAYLEIGH,NEW}, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH (-1: sched[])
@@ -171,9 +171,9 @@ void read_env_knobs(DeviceModel& D) {
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   DeviceModel::Knobs k;
   k.exterior_mode = env_int("MCGPU_EXTERIOR_MODE", 3);
-  k.compat_thresh[0] = env_int("MCGPU_COMPAT_THRESH_COMPTON", 20);
-  k.compat_thresh[1] = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", 6);
-  k.compat_thresh[2] = env_int("MCGPU_COMPAT_THRESH_NEW", 24);
+  k.compat_thresh[0] = env_int("MCGPU_COMPAT_THRESH_COMPTON", -1);
+  k.compat_thresh[1] = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", -1);
+  k.compat_thresh[2] = env_int("MCGPU_COMPAT_THRESH_NEW", -1);
   k.blocks_per_cu = std::max(0, env_int("MCGPU_BLOCKS_PER_CU", 0));
   k.grid_spare_percent = std::max(0, env_int("MCGPU_GRID_SPARE_PERCENT", 0));
   static const char* const kSched[5] = {"MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH"};
@@ -687,9 +687,17 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
 
   A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? D.knobs.exterior_mode : 0;  // bit 0: hop during flight, bit 1: hop at the source
   // batching thresholds of the COMPAT kernel (lanes of a wave64, one history per lane)
-  A.thresh_compton = D.knobs.compat_thresh[0];
-  A.thresh_rayleigh = D.knobs.compat_thresh[1];
-  A.thresh_new = D.knobs.compat_thresh[2];
+  // The Compton batch of the COMPAT kernel walks every electron shell of the material several times in the reference's own
+  // arithmetic: with tissue tables (29-40 shells) it is 60-73 % of the kernel and wants FULL batches -- threshold 40 of 64 lanes
+  // instead of 20: thorax +39 %, CIRS +32 % (tools/compat_sweep.py) -- while the 4-12 shells of the Catphan's plastics prefer
+  // photons back in flight early (40: -21 %).  Chosen from the mean shell count of the materials in use; tallies do not depend on it.
+  int shells = 0, used = 0;
+  for (int m = 0; m < kMaxMaterials; ++m)
+    if (D.compact_of[m] >= 0) { shells += std::min(H.mat.noscco[m], kMaxShells); ++used; }
+  const bool many_shells = used > 0 && shells >= 20 * used;
+  A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 40 : 20);
+  A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : (many_shells ? 8 : 6);
+  A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : 24;
   return A;
 }
 
