@@ -300,6 +300,8 @@ def other_workloads(eng, torch, H, projections, device):
                                                                                      "l2_hit_rate", "traffic_source", "algorithmic_bytes_per_history")},
                        "valu_issue": valu, "volume_bytes": c2.geti("volume_bytes_device"), "materials_used": c2.geti("num_materials_used"),
                        "detected_energy_units_last_projection": detected,
+                       # the bit-exact personality on this workload (reference arithmetic, RANECU streams), driver-timed like the rest
+                       "compat": {k: v for k, v in compat_leg(c2, torch, H, launches=2).items() if k != "what"},
                        "prepare_inputs_s": t1 - t0, "load_measure_s": time.perf_counter() - t1}
     return out
 
