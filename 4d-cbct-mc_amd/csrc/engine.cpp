@@ -691,13 +691,15 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   // arithmetic: with tissue tables (29-40 shells) it is 60-73 % of the kernel and wants FULL batches -- threshold 40 of 64 lanes
   // instead of 20: thorax +39 %, CIRS +32 % (tools/compat_sweep.py) -- while the 4-12 shells of the Catphan's plastics prefer
   // photons back in flight early (40: -21 %).  Chosen from the mean shell count of the materials in use; tallies do not depend on it.
+  // Second sweep: the tally/source batch is cheap and should not hold lanes back (24 -> 12..16 lanes), which in turn lets the
+  // Compton batch wait for 48: thorax 1.9e8 -> 2.95e8, CIRS 4.6e8 -> 6.5e8, Catphan 1.58e9 -> 1.66e9 histories/s.
   int shells = 0, used = 0;
   for (int m = 0; m < kMaxMaterials; ++m)
     if (D.compact_of[m] >= 0) { shells += std::min(H.mat.noscco[m], kMaxShells); ++used; }
   const bool many_shells = used > 0 && shells >= 20 * used;
-  A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 40 : 20);
-  A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : (many_shells ? 8 : 6);
-  A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : 24;
+  A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 48 : 20);
+  A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : 4;
+  A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 12 : 16);
   return A;
 }
 
