@@ -145,6 +145,12 @@ def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, 
             a, _, _ = dev.run_projection(p, 400_000, mode="fast", seed=9)
             b, _, _ = ref.run_projection(p, 400_000, mode="fast", seed=9)
             assert np.array_equal(a, b) and a.sum() > 0
+        # a clone of the warped context downloads (and un-tiles) the device-resident voxels: same geometry, same tallies
+        with dev.clone(0) as twin:
+            assert np.array_equal(twin.host_table("voxel_mat_dens"), ref.host_table("voxel_mat_dens"))
+            a, _, _ = twin.run_projection(1, 300_000, mode="fast", seed=4)
+            b, _, _ = dev.run_projection(1, 300_000, mode="fast", seed=4)
+            assert np.array_equal(a, b) and a.sum() > 0
         # a second state warps the BASE geometry again (not the warped one), and the identity field restores it
         dev.warp_geometry(np.zeros_like(field), frame="geometry")
         with engine.create(base, device=0) as fresh:
