@@ -133,6 +133,7 @@ struct TrackArgs {
   unsigned int stream_key;  // FAST: projection index mixed into the Philox key
   // COMPAT kernel: parked lanes per wave64 that trigger a batched service of that kind
   int thresh_compton, thresh_rayleigh, thresh_new;
+  int thresh_take;  // COMPAT: lanes whose parked history could fly while their register history cannot, to exchange the two
   int dose_flags;             // bit 0: material dose tally, bit 1: voxel dose tally (TrackCold holds the buffers)
   unsigned long long* stats;  // diagnostic build only (kNumStats counters), else null
   unsigned long long* work_counter;  // FAST: kNumCounters id dispensers, kCounterStride words apart (zeroed before each launch)

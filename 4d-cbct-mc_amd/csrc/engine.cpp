@@ -105,7 +105,7 @@ struct DeviceModel {
   // mcgpu_reload_env_knobs: the launch path itself never looks at the environment and never synchronises.
   struct Knobs {
     int exterior_mode = 3;                           // MCGPU_EXTERIOR_MODE: bit 0 hop during flight, bit 1 hop at the source
-    int compat_thresh[3] = {-1, -1, -1};             // MCGPU_COMPAT_THRESH_{COMPTON,RAYLEIGH,NEW}; -1: chosen from the materials (make_args)
+    int compat_thresh[4] = {-1, -1, -1, -1};         // MCGPU_COMPAT_THRESH_{COMPTON,RAYLEIGH,NEW,TAKE}; -1: chosen from the materials (make_args)
     int blocks_per_cu = 0;                           // MCGPU_BLOCKS_PER_CU (0: ask the occupancy API)
     int grid_spare_percent = 0;                      // MCGPU_GRID_SPARE_PERCENT
     int sched_override[5] = {-1, -1, -1, -1, -1};    // MCGPU_THRESH_{COMPTON,RAYLEIGH,NEW}, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH (-1: sched[])
@@ -174,6 +174,7 @@ void read_env_knobs(DeviceModel& D) {
   k.compat_thresh[0] = env_int("MCGPU_COMPAT_THRESH_COMPTON", -1);
   k.compat_thresh[1] = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", -1);
   k.compat_thresh[2] = env_int("MCGPU_COMPAT_THRESH_NEW", -1);
+  k.compat_thresh[3] = env_int("MCGPU_COMPAT_THRESH_TAKE", -1);
   k.blocks_per_cu = std::max(0, env_int("MCGPU_BLOCKS_PER_CU", 0));
   k.grid_spare_percent = std::max(0, env_int("MCGPU_GRID_SPARE_PERCENT", 0));
   static const char* const kSched[5] = {"MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH"};
@@ -686,13 +687,16 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.dose_flags = D.dose_flags;
 
   A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? D.knobs.exterior_mode : 0;  // bit 0: hop during flight, bit 1: hop at the source
-  // batching thresholds of the COMPAT kernel (lanes of a wave64, one history per lane)
+  // batching thresholds of the COMPAT kernel (lanes of a wave64 holding such a history in their registers or their parking slot)
   // The Compton batch of the COMPAT kernel walks every electron shell of the material several times in the reference's own
   // arithmetic: with tissue tables (29-40 shells) it is 60-73 % of the kernel and wants FULL batches -- threshold 40 of 64 lanes
   // instead of 20: thorax +39 %, CIRS +32 % (tools/compat_sweep.py) -- while the 4-12 shells of the Catphan's plastics prefer
   // photons back in flight early (40: -21 %).  Chosen from the mean shell count of the materials in use; tallies do not depend on it.
   // Second sweep: the tally/source batch is cheap and should not hold lanes back (24 -> 12..16 lanes), which in turn lets the
   // Compton batch wait for 48: thorax 1.9e8 -> 2.95e8, CIRS 4.6e8 -> 6.5e8, Catphan 1.58e9 -> 1.66e9 histories/s.
+  // Round 3, with resumable Compton trials and two batches per lane (track_kernel.inc), the same thresholds are still the best of
+  // the sweep (profiles/r03u_compat_sweep.txt): thorax 4.1e8, CIRS 9.2e8, Catphan 1.8e9; exchanging the two histories of a lane
+  // pays from 1-8 takers on (thresh_take), 16+ loses.
   int shells = 0, used = 0;
   for (int m = 0; m < kMaxMaterials; ++m)
     if (D.compact_of[m] >= 0) { shells += std::min(H.mat.noscco[m], kMaxShells); ++used; }
@@ -700,6 +704,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 48 : 20);
   A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : 4;
   A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 12 : 16);
+  A.thresh_take = D.knobs.compat_thresh[3] >= 0 ? D.knobs.compat_thresh[3] : 4;
   return A;
 }
 
@@ -874,7 +879,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
   else if (k == "sigma_bracket_shift") *value = ctx->dev.sig_shift;
-  else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots;
+  else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots + 16 * kTrackBlockThreads * 4;  // tables + one parked history per lane (track_kernel.inc)
   else return set_error(-2, std::string("unknown integer key: ") + key);
   return 0;
   ABI_END

@@ -1,10 +1,10 @@
 """COMPAT personality: histories/s on a bench workload for a set of batching thresholds (GPU).
-usage: compat_sweep.py <workload dir> "tC,tR,tN" ...   (MCGPU_COMPAT_THRESH_COMPTON / _RAYLEIGH / _NEW; tallies do not depend on them)"""
+usage: compat_sweep.py <workload dir> "tC,tR,tN[,tTake]" ...   (MCGPU_COMPAT_THRESH_COMPTON / _RAYLEIGH / _NEW; tallies do not depend on them)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import cases
 eng = cases.pkg.engine
-KEYS = ("MCGPU_COMPAT_THRESH_COMPTON", "MCGPU_COMPAT_THRESH_RAYLEIGH", "MCGPU_COMPAT_THRESH_NEW")
+KEYS = ("MCGPU_COMPAT_THRESH_COMPTON", "MCGPU_COMPAT_THRESH_RAYLEIGH", "MCGPU_COMPAT_THRESH_NEW", "MCGPU_COMPAT_THRESH_TAKE")
 with eng.create(sys.argv[1] + "/input.in", device=0) as ctx:
     batches, hpt, total = ctx.reference_shape(int(float(os.environ.get("H", "2e7"))))
     ref = None
