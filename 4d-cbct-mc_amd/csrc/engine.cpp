@@ -879,7 +879,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
   else if (k == "sigma_bracket_shift") *value = ctx->dev.sig_shift;
-  else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots + 16 * kTrackBlockThreads * 4;  // tables + one parked history per lane (track_kernel.inc)
+  else if (k == "lds_bytes_compat") *value = ctx->dev.lds.slots + 14 * kTrackBlockThreads * 4;  // tables + one parked history per lane (track_kernel.inc)
   else return set_error(-2, std::string("unknown integer key: ") + key);
   return 0;
   ABI_END
