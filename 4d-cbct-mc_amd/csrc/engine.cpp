@@ -28,6 +28,7 @@ int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
+hipError_t launch_kat_expf(int n, const float* x, float* e, hipStream_t stream);
 hipError_t launch_warp(int nx, int ny, int nz, const unsigned char* mat, const float* dens, const float* dvf, unsigned char default_mat,
                        float default_dens, unsigned char* out_mat, float* out_dens, hipStream_t stream);
 hipError_t launch_finalize(unsigned long long* image, int nx, int nz, int crop_nx, double norm, float* planes, int clear, hipStream_t stream);
@@ -1577,6 +1578,22 @@ int mcgpu_kat_math(mcgpu_ctx* ctx, int n, const double* x, double* out_log, doub
   if (e == hipSuccess) e = hipMemcpy(out_exp, d + 2 * n, nb, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(out_sin, d + 3 * n, nb, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(out_cos, d + 4 * n, nb, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_kat_expf(mcgpu_ctx* ctx, int n, const float* x, float* out_exp) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && x && out_exp && n > 0, -1, "!!ERROR!! mcgpu_kat_expf: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  float* d = nullptr;
+  const size_t nb = (size_t)n * 4;
+  HIP_TRY(hipMalloc((void**)&d, 2 * nb));
+  hipError_t e = hipMemcpy(d, x, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_kat_expf(n, d, d + n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out_exp, d + n, nb, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   HIP_TRY(e);
   return 0;

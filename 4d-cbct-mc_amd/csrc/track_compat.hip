@@ -22,6 +22,12 @@ __global__ void kat_math(int n, const double* x, double* l, double* e, double* s
   s[i] = sn;
   c[i] = cs;
 }
+__global__ void kat_expf(int n, const float* x, float* e) {
+  stage_exp2_table();
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) e[i] = mc_expf(x[i]);  // the function the COMPAT kernel calls
+}
 }  // namespace
 
 hipError_t launch_kat_rng_fast(int seed, int hist, int n, float* out_dev, hipStream_t stream);
@@ -35,6 +41,10 @@ hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* 
 }
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream) {
   hipLaunchKernelGGL(kat_math, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, l, e, s, c);
+  return hipGetLastError();
+}
+hipError_t launch_kat_expf(int n, const float* x, float* e, hipStream_t stream) {
+  hipLaunchKernelGGL(kat_expf, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, e);
   return hipGetLastError();
 }
 }  // namespace mcgpu

@@ -291,6 +291,8 @@ int mcgpu_write_voxel_binary(const char *path, const int n[3], const float spaci
 /* Device-side known-answer hooks used by the parity tests (each runs a tiny kernel on the context's device). */
 int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n, float *out_f32);
 int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, double *out_exp, double *out_sin, double *out_cos);
+/* expf as the COMPAT kernel evaluates it (the C library's single-precision algorithm, track_common.inc gl_expf) */
+int mcgpu_kat_expf(mcgpu_ctx *ctx, int n, const float *x, float *out_exp);
 
 /* ------------------------------------------------------------------------------------------------
  * Row f4: FDK reconstruction of a projection stack (what the reference obtains from `rtkfdk --hardware cuda`,

@@ -9,9 +9,9 @@
  * -ffp-contract=off and without fast-math (oracle/Makefile).
  *
  * ORACLE_MATH_PORTABLE swaps the libm calls inside the history loop (logf, expf, powf, sin,
- * cos) for the deterministic "pm_" functions below, which use only IEEE +,-,*,/ on doubles
- * and bit manipulation; the HIP compat kernel restates the same functions, which makes
- * GPU-vs-oracle comparisons bit-exact.
+ * cos) for the deterministic functions below ("pm_": IEEE +,-,*,/ on doubles and bit moves;
+ * "gl_expf": the C library's own single-precision algorithm with explicit fma); the HIP compat
+ * kernel restates the same functions, which makes GPU-vs-oracle comparisons bit-exact.
  */
 #include "mcgpu_oracle.h"
 
@@ -46,7 +46,8 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------
  * Portable math.  Algorithms: log via 2*atanh((m-1)/(m+1)) series on m in [sqrt(1/2),sqrt(2));
  * exp via Cody-Waite reduction by ln2 and a degree-13 Taylor polynomial; sin/cos via reduction
- * by pi/2 (two-part constant) and Taylor polynomials on |r| <= pi/4.  No fma, no libm.
+ * by pi/2 (two-part constant) and Taylor polynomials on |r| <= pi/4.  No fma, no libm.  (pm_exp now serves powf only:
+ * expf of this mode is gl_expf below.)
  * ------------------------------------------------------------------------------------------ */
 static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
@@ -101,6 +102,47 @@ static inline double pm_exp(double x)
   return (p * s1) * s2;
 }
 
+/* expf of the portable mode: the single-precision exp algorithm of the C library the reference's CPU build calls (glibc
+ * 2.35 sysdeps/ieee754/flt-32/e_expf.c, i.e. the ARM "optimized routines" expf: exp(x) = 2^(k/32) 2^(r/32) with
+ * k + r = 32 x / ln2, |r| <= 1/2, a 32-entry table for the first factor and a cubic for the second, all in double, ONE
+ * rounding to float at the end), written in the form x86-64 machines with FMA execute it (every multiply-add one fused
+ * operation, spelled fma() here).  The table is generated by oracle/gen_exp2f_table.py (pure arithmetic); the scalar
+ * constants are those of the published algorithm.  oracle/check_libm.c compares the function with the host libm's expf()
+ * over all floats: 0 of 4 278 190 082 differ on the build machine (tests/test_oracle_golden.py repeats a sampled
+ * comparison).  It replaces the degree-13 Taylor polynomial this mode used for expf before (170 648 floats differed from
+ * libm), at a third of the operations -- expf is called twice per electron shell in every Compton angle trial.
+ * logf, powf, sin and cos of this mode remain the pm_ functions above / below. */
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static const uint64_t GL_EXP2_T[32] = {
+  0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+  0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+  0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+  0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+  0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+  0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+static inline float gl_expf(float x)
+{
+  const uint32_t abstop = (f2u(x) >> 20) & 0x7ff;
+  if (abstop >= (0x42b00000u >> 20)) {            /* |x| >= 88, inf or nan */
+    if (f2u(x) == 0xff800000u) return 0.0f;
+    if (abstop >= (0x7f800000u >> 20)) return x + x;
+    if (x > 0x1.62e42ep6f) return INFINITY;       /* x > log(0x1p128) */
+    if (x < -0x1.9fe368p6f) return 0.0f;          /* x < log(0x1p-150) */
+    if (x < -0x1.9d1d9ep6f) return 0x1p-149f;     /* x < log(0x1p-149): the library's "may underflow" value */
+  }
+  const double xd = (double)x;
+  double kd = fma(0x1.71547652b82fep+5, xd, 0x1.8p+52);          /* 32/ln2 * x, rounded to an integer by the shift */
+  const uint64_t ki = d2u(kd);
+  kd -= 0x1.8p+52;
+  const double r = fma(0x1.71547652b82fep+5, xd, -kd);
+  const double s = u2d(GL_EXP2_T[ki % 32] + (ki << 47));          /* 2^(k/32) */
+  const double z = fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+  const double r2 = r * r;
+  double y = fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+  y = fma(z, r2, y);
+  return (float)(y * s);
+}
+
 static inline void pm_sincos(double x, double *sn, double *cs)
 {
   double kf = floor(x * 0.63661977236758138 + 0.5);
@@ -136,11 +178,12 @@ static inline void pm_sincos(double x, double *sn, double *cs)
 
 double oracle_pm_log(double x) { return pm_log(x); }
 double oracle_pm_exp(double x) { return pm_exp(x); }
+float oracle_gl_expf(float x) { return gl_expf(x); }
 void oracle_pm_sincos(double x, double *s, double *c) { pm_sincos(x, s, c); }
 
 /* math dispatch ---------------------------------------------------------------------------- */
 static inline float m_logf(float x, int pm) { return pm ? (float)pm_log((double)x) : logf(x); }
-static inline float m_expf(float x, int pm) { return pm ? (float)pm_exp((double)x) : expf(x); }
+static inline float m_expf(float x, int pm) { return pm ? gl_expf(x) : expf(x); }
 static inline float m_powf(float b, float y, int pm) { return pm ? (float)pm_exp((double)y * pm_log((double)b)) : powf(b, y); }
 static inline void m_sincos(double x, double *s, double *c, int pm)
 { if (pm) pm_sincos(x, s, c); else { *s = sin(x); *c = cos(x); } }

@@ -59,6 +59,11 @@ _oracle = None
 def oracle():
     global _oracle
     if _oracle is None:
+        try:  # oracle/Makefile builds with -mfma (the explicit fma() calls of gl_expf)
+            if "fma" not in next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split():
+                raise RuntimeError("oracle/liboracle.so needs a CPU with FMA3 (oracle/Makefile: -mfma)")
+        except (OSError, StopIteration):
+            pass
         lib = C.CDLL(str(ensure_oracle_built()))
         lib.oracle_track.argtypes = [C.POINTER(OracleTables), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.c_int, C.POINTER(OracleCounters)]
@@ -70,6 +75,8 @@ def oracle():
         lib.oracle_pm_log.argtypes = [C.c_double]
         lib.oracle_pm_exp.restype = C.c_double
         lib.oracle_pm_exp.argtypes = [C.c_double]
+        lib.oracle_gl_expf.restype = C.c_float
+        lib.oracle_gl_expf.argtypes = [C.c_float]
         lib.oracle_pm_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.oracle_rotate.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
         lib.oracle_gcoa.argtypes = [C.POINTER(OracleTables), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]

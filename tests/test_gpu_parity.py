@@ -37,6 +37,19 @@ def test_portable_math_bit_exact(gpu_engine, case_dir):
             assert sn[i] == s.value and cs[i] == c.value
 
 
+def test_compat_expf_bit_exact(gpu_engine, case_dir):
+    """expf as the COMPAT kernel evaluates it == the oracle's gl_expf (which equals the host libm on every float,
+    oracle/check_libm.c), incl. the underflow corner and subnormal results."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-110.0, 0.5, 200000), rng.uniform(-1e-3, 1e-3, 20000), rng.uniform(0.5, 89.5, 20000),
+                        [-103.97, -103.5, -103.28, -103.2, -150.0, 88.7, 88.8, 0.0, -0.0, 0.5, -np.inf]]).astype(np.float32)
+    lib = ol.oracle()
+    want = np.array([lib.oracle_gl_expf(float(v)) for v in x], dtype=np.float32)
+    with gpu_engine.create(case_dir("air"), device=0) as ctx:
+        got = ctx.kat_expf(x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_ranecu_stream_bit_exact(gpu_engine, case_dir):
     import ctypes as C
     with gpu_engine.create(case_dir("air"), device=0) as ctx:

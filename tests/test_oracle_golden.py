@@ -6,6 +6,7 @@ only through an explicit, tiny budget).  ORACLE_MATH_PORTABLE must reproduce its
 on any machine -- it uses no libm.
 """
 import ctypes as C
+import re
 
 import numpy as np
 import pytest
@@ -91,6 +92,34 @@ def test_portable_math_accuracy():
         s, c = C.c_double(), C.c_double()
         lib.oracle_pm_sincos(v, C.byref(s), C.byref(c))
         assert abs(s.value - np.sin(v)) < 4e-16 and abs(c.value - np.cos(v)) < 4e-16
+
+
+def test_portable_expf_is_the_host_libm_expf():
+    """gl_expf restates the C library's single-precision exp algorithm; on the build machine it equals libm's expf() on every
+    float (oracle/check_libm.c, 4 278 190 082 inputs).  Here: every 4099th float plus the argument range the history loop uses,
+    against the expf() of the machine the tests run on, and the table against its generator."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_exp2f_table", ol.ROOT / "oracle" / "gen_exp2f_table.py")
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    src = (ol.ROOT / "oracle" / "mcgpu_oracle.c").read_text()
+    body = src[src.index("GL_EXP2_T[32] = {"):]
+    body = body[:body.index("};")]
+    assert [int(t, 16) for t in re.findall(r"0x[0-9a-f]{16}", body)] == gen.table()
+    dev = (ol.ROOT / "4d-cbct-mc_amd" / "csrc" / "track_common.inc").read_text()
+    body = dev[dev.index("kExp2Table[32] = {"):]
+    body = body[:body.index("};")]
+    assert [int(t, 16) for t in re.findall(r"0x[0-9a-f]{16}", body)] == gen.table()
+    lib = ol.oracle()
+    libm = C.CDLL("libm.so.6")
+    libm.expf.restype = C.c_float
+    libm.expf.argtypes = [C.c_float]
+    bits = np.concatenate([np.arange(0, 2**32, 4099 * 64, dtype=np.uint64).astype(np.uint32),
+                           np.random.default_rng(5).uniform(-104.5, 0.5, 40000).astype(np.float32).view(np.uint32)])
+    x = bits.view(np.float32)
+    x = x[~np.isnan(x)]
+    got = np.array([lib.oracle_gl_expf(float(v)) for v in x], dtype=np.float32)
+    want = np.array([libm.expf(float(v)) for v in x], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
