@@ -702,9 +702,9 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   for (int m = 0; m < kMaxMaterials; ++m)
     if (D.compact_of[m] >= 0) { shells += std::min(H.mat.noscco[m], kMaxShells); ++used; }
   const bool many_shells = used > 0 && shells >= 20 * used;
-  A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 48 : 20);
+  A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 48 : 32);
   A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : 4;
-  A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 12 : 16);
+  A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 12 : 24);
   A.thresh_take = D.knobs.compat_thresh[3] >= 0 ? D.knobs.compat_thresh[3] : 4;
   return A;
 }
