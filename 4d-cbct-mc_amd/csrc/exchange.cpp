@@ -287,6 +287,28 @@ int mcgpu_exchange_connect_local(mcgpu_exchange* x, mcgpu_exchange* peer) {
   X_END
 }
 
+// After every peer is connected and BEFORE the first step: one small copy-engine transfer into this rank's slot of every
+// peer's landing buffer, waited for -- the same call, copy kind and stream as the pushes of mcgpu_exchange_submit.  A platform on
+// which that transfer cannot reach a peer (no copy-engine path between two devices, a mapping that only kernels may touch) fails
+// here, where the caller can still agree with the other ranks on another route, instead of in the middle of a scan.  The bytes
+// written are overwritten by the first real push into that slot.
+int mcgpu_exchange_probe(mcgpu_exchange* x) {
+  X_BEGIN
+  X_REQUIRE(x, "!!ERROR!! mcgpu_exchange_probe: bad argument");
+  X_REQUIRE(x->last_submitted < 0, "!!ERROR!! mcgpu_exchange_probe: call it before the first step");
+  X_HIP(hipSetDevice(x->device));
+  const size_t bytes = (size_t)std::min<unsigned long long>(x->words, 512ULL) * 8;
+  for (int o = 0; o < x->world; ++o) {
+    if (o == x->rank) continue;
+    X_REQUIRE(x->connected[o], "!!ERROR!! mcgpu_exchange_probe: a peer is not connected");
+    for (int q = 0; q < 2; ++q)
+      X_HIP(hipMemcpyAsync(x->slot(x->peer_landing[o], x->rank, q), x->tally[q], bytes, hipMemcpyDeviceToDeviceNoCU, x->copy));
+  }
+  X_HIP(hipStreamSynchronize(x->copy));
+  return 0;
+  X_END
+}
+
 int mcgpu_exchange_owner(const mcgpu_exchange* x, long long step) { return x ? x->owner(step) : -1; }
 
 // The tally buffer of `step` (parity step & 1), zeroed on `stream`.  The buffer's previous user was step - 2: its push

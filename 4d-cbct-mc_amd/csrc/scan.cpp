@@ -176,6 +176,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     for (int g = 0; g < n_ctx; ++g)
       for (int h = 0; h < n_ctx; ++h)
         if (g != h) ABI_OK(mcgpu_exchange_connect_local(D[g].x, D[h].x));
+    for (int g = 0; g < n_ctx; ++g) ABI_OK(mcgpu_exchange_probe(D[g].x));  // the copy engines reach every peer, or the scan stops here
     HIP_OK(hipSetDevice(D[0].dev));
     if (by_time) {
       const unsigned long long probe = 4000000ULL;

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
     "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
     "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
-    "mcgpu_exchange_connect_local", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
+    "mcgpu_exchange_connect_local", "mcgpu_exchange_probe", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
     "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
 )
 
@@ -128,6 +128,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_exchange_connect.argtypes = [vp, ci, vp, C.c_size_t]
     lib.mcgpu_exchange_connect_local.argtypes = [vp, vp]
     lib.mcgpu_exchange_owner.argtypes = [vp, C.c_longlong]
+    lib.mcgpu_exchange_probe.argtypes = [vp]
     lib.mcgpu_exchange_begin.argtypes = [vp, C.c_longlong, vp, C.POINTER(vp)]
     lib.mcgpu_exchange_submit.argtypes = [vp, C.c_longlong, vp]
     lib.mcgpu_exchange_collect.argtypes = [vp, C.c_longlong, vp, C.POINTER(vp)]
@@ -275,6 +276,10 @@ class Exchange:
 
     def connect_local(self, other: "Exchange"):
         _check(self.lib.mcgpu_exchange_connect_local(self.h, other.h))
+
+    def probe(self):
+        """One small copy-engine transfer to every connected peer, waited for (before the first step)."""
+        _check(self.lib.mcgpu_exchange_probe(self.h))
 
     def owner(self, step: int) -> int:
         return int(self.lib.mcgpu_exchange_owner(self.h, int(step)))

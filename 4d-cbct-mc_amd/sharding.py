@@ -115,6 +115,13 @@ def connect_exchange(x, dist):
             err = e
     flags = [None] * world
     dist.all_gather_object(flags, err is None)  # also the barrier: nobody starts pushing before everybody has mapped everybody
+    if not all(flags):
+        return False, err
+    try:  # everybody is mapped: can the copy engine of this device reach every peer's landing buffer?
+        x.probe()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    dist.all_gather_object(flags, err is None)
     return all(flags), err
 
 

@@ -239,6 +239,9 @@ int mcgpu_exchange_create(int device_id, int rank, int world, size_t words, int 
 int mcgpu_exchange_card(mcgpu_exchange *x, unsigned char *card, size_t card_bytes);
 int mcgpu_exchange_connect(mcgpu_exchange *x, int peer, const unsigned char *card, size_t card_bytes);
 int mcgpu_exchange_connect_local(mcgpu_exchange *x, mcgpu_exchange *peer);
+/* after all peers are connected, before the first step: one small copy-engine transfer into every peer's landing buffer, waited
+ * for -- a platform without that path between two devices fails here, where the ranks can still agree on another route */
+int mcgpu_exchange_probe(mcgpu_exchange *x);
 int mcgpu_exchange_owner(const mcgpu_exchange *x, long long step);
 int mcgpu_exchange_begin(mcgpu_exchange *x, long long step, void *hip_stream, void **tally_dev);
 int mcgpu_exchange_submit(mcgpu_exchange *x, long long step, void *hip_stream);

@@ -34,6 +34,7 @@ with eng.create(inp, device=0) as ctx:
     (scratch / f"connected_{rank}").write_text("1")
     for peer in range(world):
         wait_for(scratch / f"connected_{peer}")
+    x.probe()  # every peer has mapped every peer: the copy engine reaches their landing buffers
     nproj, seed = ctx.num_projections, ctx.geti("seed")
     for k in range(steps + 1):
         if k < steps:

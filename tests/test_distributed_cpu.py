@@ -96,8 +96,8 @@ def test_two_rank_history_sharding_reduces_to_single_process_image(case_dir, tmp
 class _FakeExchange:
     """Stands in for engine.Exchange where there is no GPU: records what the handshake hands it."""
 
-    def __init__(self, rank, world):
-        self.rank, self.world, self.connected = rank, world, {}
+    def __init__(self, rank, world, probe_fails=False):
+        self.rank, self.world, self.connected, self.probed, self.probe_fails = rank, world, {}, 0, probe_fails
 
     def card(self):
         return bytes([self.rank]) * 64 * (3 + 2 * self.world)
@@ -105,6 +105,12 @@ class _FakeExchange:
     def connect(self, peer, card):
         assert peer != self.rank and peer not in self.connected
         self.connected[peer] = card
+
+    def probe(self):
+        assert len(self.connected) == self.world - 1  # only after every peer is mapped
+        self.probed += 1
+        if self.probe_fails:
+            raise RuntimeError("the copy engine cannot reach a peer")
 
 
 def _handshake_worker(rank, world, port, shm_path, out_dir):
@@ -124,8 +130,11 @@ def _handshake_worker(rank, world, port, shm_path, out_dir):
     assert len(m) == eng.Exchange.shared_bytes(world) and bytes(m[:]) == b"\0" * len(m)
     fx = _FakeExchange(rank, world)
     ok, err = cases.pkg.sharding.connect_exchange(fx, dist)
-    assert ok and err is None
+    assert ok and err is None and fx.probed == 1
     assert sorted(fx.connected) == [r for r in range(world) if r != rank]
+    # the copy-engine probe fails on ONE rank: both ranks get the same verdict and take the same fallback
+    ok, err = cases.pkg.sharding.connect_exchange(_FakeExchange(rank, world, probe_fails=(rank == 0)), dist)
+    assert not ok and (err is not None) == (rank == 0)
     # a rank without an exchange end (its device refused IPC, say): EVERY rank learns it, nobody is left in a collective
     ok, err = cases.pkg.sharding.connect_exchange(None if rank == 1 else _FakeExchange(rank, world), dist)
     assert not ok and err is not None

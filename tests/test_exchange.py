@@ -42,6 +42,8 @@ def test_exchange_between_contexts_of_one_process(engine, case_dir, world, polic
             for b in xs:
                 if a is not b:
                     a.connect_local(b)
+        for a in xs:
+            a.probe()
         nproj, seed = ctxs[0].num_projections, ctxs[0].geti("seed")
         reduced = {}
         for k in range(steps + 1):
@@ -63,6 +65,8 @@ def test_exchange_between_contexts_of_one_process(engine, case_dir, world, polic
             assert np.array_equal(reduced[k], alone) and alone.sum() > 0, k
         with pytest.raises(engine.EngineError):  # a step is collected once
             xs[0].collect(steps - 1)
+        with pytest.raises(engine.EngineError):  # the probe belongs before the first step
+            xs[0].probe()
         if world > 1:
             st = [x.stats() for x in xs]
             assert sum(s["pushes"] for s in st) == steps * (world - 1) and sum(s["collects"] for s in st) == steps
