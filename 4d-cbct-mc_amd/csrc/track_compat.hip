@@ -13,6 +13,8 @@ __global__ void kat_ranecu(int seed, int batch, int hpt, int n, float* out) {
   for (int i = 0; i < n; ++i) out[i] = rng_f(r);
 }
 __global__ void kat_math(int n, const double* x, double* l, double* e, double* s, double* c) {
+  stage_exp2_table();
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   l[i] = pm_log(x[i]);

@@ -44,7 +44,7 @@ typedef struct {
 } det_t;
 
 /* ------------------------------------------------------------------------------------------
- * Portable math.  Algorithms: log via 2*atanh((m-1)/(m+1)) series on m in [sqrt(1/2),sqrt(2));
+ * Portable math.  Algorithms: log via a 64-entry table and the Taylor polynomial of log1p (pm_log below);
  * exp via Cody-Waite reduction by ln2 and a degree-13 Taylor polynomial; sin/cos via reduction
  * by pi/2 (two-part constant) and Taylor polynomials on |r| <= pi/4.  No fma, no libm.  (pm_exp now serves powf only:
  * expf of this mode is gl_expf below.)
@@ -52,27 +52,60 @@ typedef struct {
 static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 
+/* ln of a positive normal double: x = 2^k z with z in [OFF, 2 OFF), OFF ~ sqrt(1/2); a 64-entry table {1/c_i, -ln(1/c_i)} for
+ * the interval of z (oracle/gen_log_table.py: pure arithmetic; c = 1 for the interval around 1.0), r = z/c - 1 by one fma,
+ * |r| < 0.008, log1p(r) by its Taylor polynomial to r^8 (error r^9/9 < 2e-20).  No division (round 2's 2 atanh series had
+ * one: a third of the instructions of a Woodcock step on the device). */
+static const double PM_LOG_T[64][2] = {
+  {0x1.680cbcd75c447p+0, -0x1.5d401699901fbp-2}, {0x1.6422f70fce190p+0, -0x1.520f66629c64ap-2},
+  {0x1.604ebbd86ed05p+0, -0x1.46fdadb7c4a33p-2}, {0x1.5c8f5b36b5f7ap+0, -0x1.3c0a43098441cp-2},
+  {0x1.58e42c98c7254p+0, -0x1.3134822a443dfp-2}, {0x1.554c8e72ab8d1p+0, -0x1.267bcc14a5204p-2},
+  {0x1.51c7e5e1a7890p+0, -0x1.1bdf86b4c6653p-2}, {0x1.4e559e553c622p+0, -0x1.115f1cb45c41bp-2},
+  {0x1.4af5293d6fae2p+0, -0x1.06f9fd496801ep-2}, {0x1.47a5fdbdf9ca4p+0, -0x1.f95f380ed4a55p-3},
+  {0x1.44679866047a0p+0, -0x1.e4fee165d342bp-3}, {0x1.41397aec297ffp+0, -0x1.d0d1ee2e52a3ep-3},
+  {0x1.3e1b2bee6741cp+0, -0x1.bcd75dbbe1f04p-3}, {0x1.3b0c36b5c7393p+0, -0x1.a90e36d289f47p-3},
+  {0x1.380c2afd77253p+0, -0x1.9575875de8192p-3}, {0x1.351a9cbd1ab0bp+0, -0x1.820c642bbdb66p-3},
+  {0x1.323723f61fa13p+0, -0x1.6ed1e8a9c1f43p-3}, {0x1.2f615c83e29d7p+0, -0x1.5bc536a687a6cp-3},
+  {0x1.2c98e5ee7644dp+0, -0x1.48e576154b88ep-3}, {0x1.29dd633fe1b19p+0, -0x1.3631d4d4821b2p-3},
+  {0x1.272e7adbae92dp+0, -0x1.23a98676fee40p-3}, {0x1.248bd658a1e75p+0, -0x1.114bc40f914ebp-3},
+  {0x1.21f5225c7cfd0p+0, -0x1.fe2f97fdeb17dp-4}, {0x1.1f6a0e79a6c4ep+0, -0x1.da19c387f3f66p-4},
+  {0x1.1cea4d0e9fc17p+0, -0x1.b6549b9b77017p-4}, {0x1.1a75932724e42p+0, -0x1.92deba9fba046p-4},
+  {0x1.180b985ee791fp+0, -0x1.6fb6c4313fd6bp-4}, {0x1.15ac16c5c2c72p+0, -0x1.4cdb64d18a57ep-4},
+  {0x1.1356cac556ee6p+0, -0x1.2a4b519a3f19bp-4}, {0x1.110b7307f780bp+0, -0x1.080547f38348dp-4},
+  {0x1.0ec9d060d6e24p+0, -0x1.cc101a9acb805p-5}, {0x1.0c91a5b55e3b4p+0, -0x1.88a4ddb8616c5p-5},
+  {0x1.0a62b7e7a03aap+0, -0x1.45c682aefd356p-5}, {0x1.083ccdc1d6c93p+0, -0x1.0372c177df6e4p-5},
+  {0x1.061fafe2dcbc4p+0, -0x1.834ec03d80f5dp-6}, {0x1.040b28ab9586fp+0, -0x1.00c4649e005fbp-6},
+  {0x1.01ff042d35cc6p+0, -0x1.fd08c72af8ec1p-8}, {0x1.0000000000000p+0, 0x0.0p+0},
+  {0x1.f80c5d11a2684p-1, 0x1.0073809b61d99p-6}, {0x1.f0698d819db27p-1, 0x1.fa8e7ea7db662p-6},
+  {0x1.e901160cae199p-1, 0x1.7873639e2b330p-5}, {0x1.e1d063d89c40fp-1, 0x1.f1cc700489fe1p-5},
+  {0x1.dad50a3b936f0p-1, 0x1.34b003beee67bp-4}, {0x1.d40cc001e9fd6p-1, 0x1.6f9d9b2997907p-4},
+  {0x1.cd755ceee8d1dp-1, 0x1.a9b53d561f1bbp-4}, {0x1.c70cd772d5babp-1, 0x1.e2fce6417493fp-4},
+  {0x1.c0d1429125649p-1, 0x1.0dbd2942908b4p-3}, {0x1.bac0cbf246f1cp-1, 0x1.299981652da3dp-3},
+  {0x1.b4d9ba1cf7947p-1, 0x1.45161f80ebbedp-3}, {0x1.af1a6ad37a2eep-1, 0x1.60358cb284e6ep-3},
+  {0x1.a98151916fce0p-1, 0x1.7afa38a290ab0p-3}, {0x1.a40cf6276378ap-1, 0x1.95667ad5d0993p-3},
+  {0x1.9ebbf37167b25p-1, 0x1.af7c93e811547p-3}, {0x1.998cf626676a3p-1, 0x1.c93eaeb33e210p-3},
+  {0x1.947ebbbe07efcp-1, 0x1.e2aee16420b79p-3}, {0x1.8f90116b2ed26p-1, 0x1.fbcf2e7e26c9fp-3},
+  {0x1.8abfd3296e17dp-1, 0x1.0a50c2e7b4a5bp-2}, {0x1.860ceadbc3a2fp-1, 0x1.1693e2ab0b8b5p-2},
+  {0x1.81764f7b3e95dp-1, 0x1.22b1dd0c26444p-2}, {0x1.7cfb04543f712p-1, 0x1.2eab9077a5f5bp-2},
+  {0x1.789a185126283p-1, 0x1.3a81d3a37b68fp-2}, {0x1.7452a5515cb7bp-1, 0x1.463575e92b4a2p-2},
+  {0x1.7023cf8bc561ap-1, 0x1.51c73f9af8e78p-2}, {0x1.6c0cc4fba9cedp-1, 0x1.5d37f2544ef66p-2}};
 static inline double pm_log(double x)
 {
-  uint64_t b = d2u(x);
-  int e = (int)((b >> 52) & 0x7ff) - 1023;
-  double m = u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-  if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
-  double f = m - 1.0;
-  double s = f / (2.0 + f);
-  double z = s * s;
-  double p = 0.047619047619047616;            /* 1/21 */
-  p = p * z + 0.052631578947368418;           /* 1/19 */
-  p = p * z + 0.058823529411764705;           /* 1/17 */
-  p = p * z + 0.066666666666666666;           /* 1/15 */
-  p = p * z + 0.076923076923076927;           /* 1/13 */
-  p = p * z + 0.090909090909090912;           /* 1/11 */
-  p = p * z + 0.11111111111111110;            /* 1/9  */
-  p = p * z + 0.14285714285714285;            /* 1/7  */
-  p = p * z + 0.20000000000000001;            /* 1/5  */
-  p = p * z + 0.33333333333333331;            /* 1/3  */
-  double r = 2.0 * s + (2.0 * s) * (z * p);
-  return (double)e * 0.69314718055994529 + r;
+  const uint64_t b = d2u(x);
+  const uint64_t tmp = b - 0x3FE6A09E00000000ULL;
+  const int i = (int)((tmp >> 46) & 63);
+  const int64_t k = (int64_t)tmp >> 52;
+  const double z = u2d(b - (tmp & 0xFFF0000000000000ULL));
+  const double r = fma(z, PM_LOG_T[i][0], -1.0);
+  double q = -0.125;
+  q = fma(q, r, 0.14285714285714285);            /*  1/7 */
+  q = fma(q, r, -0.16666666666666666);           /* -1/6 */
+  q = fma(q, r, 0.20000000000000001);            /*  1/5 */
+  q = fma(q, r, -0.25);
+  q = fma(q, r, 0.33333333333333331);            /*  1/3 */
+  q = fma(q, r, -0.5);
+  const double hi = fma((double)k, 0.69314718055994529, PM_LOG_T[i][1]);
+  return hi + fma(r * r, q, r);
 }
 
 static inline double pm_exp(double x)

@@ -105,10 +105,19 @@ def test_portable_expf_is_the_host_libm_expf():
     body = src[src.index("GL_EXP2_T[32] = {"):]
     body = body[:body.index("};")]
     assert [int(t, 16) for t in re.findall(r"0x[0-9a-f]{16}", body)] == gen.table()
-    dev = (ol.ROOT / "4d-cbct-mc_amd" / "csrc" / "track_common.inc").read_text()
+    dev = (ol.ROOT / "4d-cbct-mc_amd" / "csrc" / "compat_math.inc").read_text()
     body = dev[dev.index("kExp2Table[32] = {"):]
     body = body[:body.index("};")]
     assert [int(t, 16) for t in re.findall(r"0x[0-9a-f]{16}", body)] == gen.table()
+    # the table of pm_log (both copies) against ITS generator
+    spec = importlib.util.spec_from_file_location("gen_log_table", ol.ROOT / "oracle" / "gen_log_table.py")
+    genl = importlib.util.module_from_spec(spec); spec.loader.exec_module(genl)
+    want = [v for pair in genl.table() for v in pair]
+    for text, name in ((src, "PM_LOG_T[64][2] = {"), (dev, "kLogTable[64][2] = {")):
+        body = text[text.index(name):]
+        body = body[:body.index("};")]
+        got = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", body)]
+        assert got == want
     lib = ol.oracle()
     libm = C.CDLL("libm.so.6")
     libm.expf.restype = C.c_float

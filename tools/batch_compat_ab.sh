@@ -1,10 +1,10 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/r03u
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_dose.py tests/test_gpu_dropin.py tests/test_gpu_fullsize.py -m gpu -x -q -k "compat or dose or executable or fullsize" 2>&1 | tail -8 | tee gpurun_out/r03u/compat_parity6.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_dose.py tests/test_gpu_dropin.py tests/test_gpu_fullsize.py -m gpu -x -q -k "compat or dose or executable or fullsize" 2>&1 | tail -8 | tee gpurun_out/r03u/compat_parity7.txt
 B="--steps 2 --warmup 1 --no-workloads --no-cpu-baseline --no-end-to-end --no-compat"
 timeout 300 python bench.py $B > /dev/null 2>&1
 for wl in cirs thorax; do timeout 200 python bench.py $B --workload $wl >/dev/null 2>&1; done
 for rep in 1 2; do for lib in build/ab/*.so; do for wl in catphan cirs thorax; do
-  echo -n "$(basename $lib) $wl " | tee -a gpurun_out/r03u/compat_straight.txt
-  MCGPU_AMD_LIB=$PWD/$lib H=1e8 timeout 100 python tools/compat_sweep.py /tmp/mcgpu_bench_${wl}_512_894 "-1,-1,-1,-1" 2>&1 | tail -1 | tee -a gpurun_out/r03u/compat_straight.txt
+  echo -n "$(basename $lib) $wl " | tee -a gpurun_out/r03u/compat_tablelog.txt
+  MCGPU_AMD_LIB=$PWD/$lib H=1e8 timeout 100 python tools/compat_sweep.py /tmp/mcgpu_bench_${wl}_512_894 "-1,-1,-1,-1" 2>&1 | tail -1 | tee -a gpurun_out/r03u/compat_tablelog.txt
 done; done; done
