@@ -271,8 +271,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     D.vol_bytes = raw.size() * 4;
     D.palette_size = 0;
     D.palette = D.put(std::vector<float>(2, 0.f));
-  } else if (index_of.size() <= 256 && (size_t)((H.voxels.n[0] + 3) / 4) * (size_t)((H.voxels.n[1] + 3) / 4) < ((size_t)1 << 24)) {
-    // (a slab of fewer than 2^24 tiles: the kernels index tiles with the 24-bit multiplier; a wider volume takes the u16 route)
+  } else if (index_of.size() <= 256) {
     D.vol_kind = kVolU8;
     {
       // the reference's default for voxels warped in from outside the volume (air: material 1 at 0.0013 g/cm^3,
