@@ -84,6 +84,29 @@ def test_compat_history_sharding_is_exact(gpu_engine, case_dir):
         assert np.array_equal(whole, a + b)
 
 
+@pytest.mark.parametrize("name", ["tissue22", "catphan64"])
+def test_compat_image_is_independent_of_its_batching(gpu_engine, case_dir, monkeypatch, name):
+    """The COMPAT kernel runs two RANECU batches per lane and serves Compton / Rayleigh / tally batches at ballot thresholds:
+    none of that may reach the tallies -- every threshold setting, an odd number of batches (one lane with a single batch), a
+    single batch, and a launch split in two give the same words."""
+    with gpu_engine.create(case_dir(name), device=0) as ctx:
+        ref, _, _ = ctx.run_projection(0, 301, mode="compat", seed=42, hpt=60)
+        for cfg in ("1,1,1,1", "64,64,64,64", "48,4,12,4", "20,8,40,32", "33,2,7,64"):
+            for k, v in zip(("MCGPU_COMPAT_THRESH_COMPTON", "MCGPU_COMPAT_THRESH_RAYLEIGH", "MCGPU_COMPAT_THRESH_NEW", "MCGPU_COMPAT_THRESH_TAKE"), cfg.split(",")):
+                monkeypatch.setenv(k, v)
+            ctx.reload_env_knobs()
+            img, _, _ = ctx.run_projection(0, 301, mode="compat", seed=42, hpt=60)
+            assert np.array_equal(img, ref), cfg
+        a, _, _ = ctx.run_projection(0, 1, mode="compat", seed=42, hpt=60, first=0)
+        b, _, _ = ctx.run_projection(0, 300, mode="compat", seed=42, hpt=60, first=1)
+        assert a.sum() > 0 and np.array_equal(a + b, ref)
+        T = parity.tables_from_context(ctx)
+        cpu, _ = T.track(0, 42, 0, 301, 60, ol.MATH_PORTABLE, n_threads=4)
+        assert np.array_equal(ref.reshape(-1), cpu)
+    for k in ("MCGPU_COMPAT_THRESH_COMPTON", "MCGPU_COMPAT_THRESH_RAYLEIGH", "MCGPU_COMPAT_THRESH_NEW", "MCGPU_COMPAT_THRESH_TAKE"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_fast_history_sharding_and_determinism(gpu_engine, case_dir):
     with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
         n = 400_000
