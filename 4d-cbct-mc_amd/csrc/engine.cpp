@@ -29,6 +29,7 @@ hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t str
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 hipError_t launch_kat_expf(int n, const float* x, float* e, hipStream_t stream);
+hipError_t launch_kat_f32(int op, int n, const float* a, const float* b, float* out, hipStream_t stream);
 hipError_t launch_warp(int nx, int ny, int nz, const unsigned char* mat, const float* dens, const float* dvf, unsigned char default_mat,
                        float default_dens, unsigned char* out_mat, float* out_dens, hipStream_t stream);
 hipError_t launch_finalize(unsigned long long* image, int nx, int nz, int crop_nx, double norm, float* planes, int clear, hipStream_t stream);
@@ -1578,6 +1579,24 @@ int mcgpu_kat_math(mcgpu_ctx* ctx, int n, const double* x, double* out_log, doub
   if (e == hipSuccess) e = hipMemcpy(out_exp, d + 2 * n, nb, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(out_sin, d + 3 * n, nb, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(out_cos, d + 4 * n, nb, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_kat_f32(mcgpu_ctx* ctx, int op, int n, const float* a, const float* b, float* inout) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && a && b && inout && n > 0 && op >= 0 && op <= 4, -1, "!!ERROR!! mcgpu_kat_f32: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  float* d = nullptr;
+  const size_t nb = (size_t)n * 4;
+  HIP_TRY(hipMalloc((void**)&d, 3 * nb));
+  hipError_t e = hipMemcpy(d, a, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + n, b, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + 2 * (size_t)n, inout, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_kat_f32(op, n, d, d + n, d + 2 * (size_t)n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(inout, d + 2 * (size_t)n, nb, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   HIP_TRY(e);
   return 0;

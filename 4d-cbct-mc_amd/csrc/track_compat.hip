@@ -30,6 +30,18 @@ __global__ void kat_expf(int n, const float* x, float* e) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) e[i] = mc_expf(x[i]);  // the function the COMPAT kernel calls
 }
+// op 0: cm_sqrtf(a), 1: sqrtf(a) (the compiler's), 2: cm_divf(a, b), 3: a / b (the compiler's), 4: shell_pz(a, b, c) -- c in out on entry
+__global__ void kat_f32(int op, int n, const float* a, const float* b, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  if (op == 0) r = cm_sqrtf(a[i]);
+  else if (op == 1) r = sqrtf(a[i]);
+  else if (op == 2) r = cm_divf(a[i], b[i]);
+  else if (op == 3) r = a[i] / b[i];
+  else r = shell_pz(a[i], b[i], out[i]);
+  out[i] = r;
+}
 }  // namespace
 
 hipError_t launch_kat_rng_fast(int seed, int hist, int n, float* out_dev, hipStream_t stream);
@@ -47,6 +59,10 @@ hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double*
 }
 hipError_t launch_kat_expf(int n, const float* x, float* e, hipStream_t stream) {
   hipLaunchKernelGGL(kat_expf, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, e);
+  return hipGetLastError();
+}
+hipError_t launch_kat_f32(int op, int n, const float* a, const float* b, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(kat_f32, dim3((n + 255) / 256), dim3(256), 0, stream, op, n, a, b, out);
   return hipGetLastError();
 }
 }  // namespace mcgpu

@@ -296,6 +296,8 @@ int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n,
 int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, double *out_exp, double *out_sin, double *out_cos);
 /* expf as the COMPAT kernel evaluates it (the C library's single-precision algorithm, track_common.inc gl_expf) */
 int mcgpu_kat_expf(mcgpu_ctx *ctx, int n, const float *x, float *out_exp);
+/* float operations of the COMPAT kernel: op 0 its lean square root, 1 sqrtf, 2 its lean quotient a/b, 3 a/b, 4 shell_pz(a, b, inout) */
+int mcgpu_kat_f32(mcgpu_ctx *ctx, int op, int n, const float *a, const float *b, float *inout);
 
 /* ------------------------------------------------------------------------------------------------
  * Row f4: FDK reconstruction of a projection stack (what the reference obtains from `rtkfdk --hardware cuda`,

@@ -50,6 +50,34 @@ def test_compat_expf_bit_exact(gpu_engine, case_dir):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_compat_lean_sqrt_and_quotient_are_the_ieee_ones(gpu_engine, case_dir):
+    """compat_math.inc: cm_sqrtf / cm_divf drop the range scaling of the compiler's IEEE sequences; on the operand ranges of the
+    electron-shell arithmetic they must return the same bits as sqrtf and / (both evaluated on the device)."""
+    rng = np.random.default_rng(23)
+    with gpu_engine.create(case_dir("air"), device=0) as ctx:
+        # square root: every float of 600 binades-slices between 1 and 1e13 (dense in the mantissa), plus random radicands
+        m = np.arange(0, 1 << 23, 7, dtype=np.uint32)
+        for e in (127, 128, 131, 140, 150, 160, 169, 170):  # exponents of 1 .. 2^43
+            x = ((np.uint32(e) << np.uint32(23)) | m).view(np.float32)
+            assert np.array_equal(ctx.kat_f32(0, x).view(np.uint32), ctx.kat_f32(1, x).view(np.uint32)), e
+        x = np.exp(rng.uniform(np.log(1.0), np.log(1e13), 2_000_000)).astype(np.float32)
+        assert np.array_equal(ctx.kat_f32(0, x).view(np.uint32), ctx.kat_f32(1, x).view(np.uint32))
+        # quotient: numerators 0 or 1e-3 .. 1e13 of either sign, divisors 1e6 .. 1e12
+        n = (np.exp(rng.uniform(np.log(1e-3), np.log(1e13), 4_000_000)) * rng.choice([-1.0, 1.0], 4_000_000)).astype(np.float32)
+        n[:1000] = 0.0
+        n[1000:2000] = -0.0
+        d = np.exp(rng.uniform(np.log(1e6), np.log(1e12), 4_000_000)).astype(np.float32)
+        assert np.array_equal(ctx.kat_f32(2, n, d).view(np.uint32), ctx.kat_f32(3, n, d).view(np.uint32))
+        # the expression itself against numpy's IEEE float32 arithmetic: fj0 (aux - u mc2) / (sqrt(aux + aux + u u) mc2)
+        fj0 = rng.uniform(1e-3, 200.0, 2_000_000).astype(np.float32)
+        u = np.exp(rng.uniform(np.log(1.0), np.log(9e4), 2_000_000)).astype(np.float32)
+        aux = (rng.uniform(0.0, 1.0, 2_000_000) * 4.5e10).astype(np.float32)
+        mc2 = np.float32(510998.918)
+        want = (fj0 * (aux - u * mc2)) / (np.sqrt(aux + aux + u * u) * mc2)
+        assert want.dtype == np.float32
+        assert np.array_equal(ctx.kat_f32(4, fj0, aux, u).view(np.uint32), want.view(np.uint32))
+
+
 def test_ranecu_stream_bit_exact(gpu_engine, case_dir):
     import ctypes as C
     with gpu_engine.create(case_dir("air"), device=0) as ctx:
