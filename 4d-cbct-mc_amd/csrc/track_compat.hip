@@ -28,7 +28,7 @@ __global__ void kat_expf(int n, const float* x, float* e) {
   stage_exp2_table();
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) e[i] = mc_expf(x[i]);  // the function the COMPAT kernel calls
+  if (i < n) e[i] = (x[i] <= 0.5f) ? mc_expf(x[i]) : gl_expf<false>(x[i]);  // mc_expf: the kernel's call (arguments <= 0.5 only)
 }
 // op 0: cm_sqrtf(a), 1: sqrtf(a) (the compiler's), 2: cm_divf(a, b), 3: a / b (the compiler's), 4: shell_pz(a, b, c) -- c in out on entry
 __global__ void kat_f32(int op, int n, const float* a, const float* b, float* out) {
