@@ -46,6 +46,7 @@ constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)
 constexpr int kSlotWords = 14;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
+constexpr int kS0Bins = 1024;            // COMPAT: energy bins of the S0 bounds (TrackCold::s0_bounds)
 constexpr int kNumStats = 32;             // scheduler counters of the diagnostic build
 constexpr int kWaveTrace = 16384;         // diagnostic build: {hardware id, first and last clock} of up to this many waves follow the counters
 constexpr int kDoseMaterials = 1, kDoseVoxels = 2;  // TrackArgs::dose_flags
@@ -94,6 +95,10 @@ struct TrackCold {
   // parked histories per wave64 that trigger a batched service of that kind; service everything well populated when
   // fewer lanes than `flyable_low` can fly; stop for a scheduling point once `swap_batch` more lanes have parked
   int thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch;
+  // COMPAT kernel: rigorous bounds [lo, hi] of S0 = S(E, theta = pi) (K.cu:1300-1314) per (compact material, energy bin of width
+  // 1 / s0_inv_w from s0_emin), float2 [mc * kS0Bins + bin]; decides most Compton angle tests without the pass that computes S0
+  const float* s0_bounds;
+  float s0_emin, s0_inv_w;
   int trade_slots;  // lanes of a wave trade their parking slots: bit 0 before flying, bit 1 before the Compton and tally/source services (MCGPU_SLOT_TRADE)
 };
 
