@@ -107,6 +107,7 @@ struct DeviceModel {
   // mcgpu_reload_env_knobs: the launch path itself never looks at the environment and never synchronises.
   struct Knobs {
     int exterior_mode = 3;                           // MCGPU_EXTERIOR_MODE: bit 0 hop during flight, bit 1 hop at the source
+    bool compat_stats = false;                       // MCGPU_COMPAT_STATS: hand the diagnostic COMPAT build its counter buffer
     int compat_thresh[4] = {-1, -1, -1, -1};         // MCGPU_COMPAT_THRESH_{COMPTON,RAYLEIGH,NEW,TAKE}; -1: chosen from the materials (make_args)
     int blocks_per_cu = 0;                           // MCGPU_BLOCKS_PER_CU (0: ask the occupancy API)
     int grid_spare_percent = 0;                      // MCGPU_GRID_SPARE_PERCENT
@@ -179,6 +180,7 @@ void read_env_knobs(DeviceModel& D) {
   k.compat_thresh[1] = env_int("MCGPU_COMPAT_THRESH_RAYLEIGH", -1);
   k.compat_thresh[2] = env_int("MCGPU_COMPAT_THRESH_NEW", -1);
   k.compat_thresh[3] = env_int("MCGPU_COMPAT_THRESH_TAKE", -1);
+  k.compat_stats = env_int("MCGPU_COMPAT_STATS", 0) != 0;
   k.blocks_per_cu = std::max(0, env_int("MCGPU_BLOCKS_PER_CU", 0));
   k.grid_spare_percent = std::max(0, env_int("MCGPU_GRID_SPARE_PERCENT", 0));
   static const char* const kSched[5] = {"MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH"};
@@ -1021,6 +1023,10 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       require(seed > 0 && seed < 2147483399, -2, "!!ERROR!! mcgpu_launch_projection: RANECU seed out of range");
       const unsigned long long blocks = (count + kTrackBlockThreads - 1) / kTrackBlockThreads;
       require(blocks <= 0x7fffffffULL, -2, "!!ERROR!! mcgpu_launch_projection: too many batches");
+      if (D.knobs.compat_stats) {  // diagnostic build only (-DMC_COMPAT_STATS): the kernel's wave-level counters
+        if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats + 3 * kWaveTrace, 0ULL));
+        A.stats = D.stats;
+      }
       HIP_TRY(launch_track_compat(A, (int)blocks, stream));
     } else {
       // persistent grid: exactly the resident workgroups (an over-subscribed grid would run a second, thin round).  No
