@@ -18,7 +18,7 @@ with eng.create(sys.argv[1] + "/input.in", device=0) as ctx:
     print(json.dumps({
         "histories": done, "ms": round(secs * 1e3, 1), "loop_iterations_per_history": r(s[0], done) , "flying_lanes_per_iteration": r(s[1], s[0]),
         "compton": {"batches_per_history": round(s[3] / done, 4), "lanes_per_batch": r(s[4], s[3]), "share_of_wave_time": round(s[5] / tot, 3),
-                    "batches_with_an_S0_pass": round(s[6] / max(s[3], 1), 4), "open_tests_per_trial": round(s[7] / max(s[4], 1), 5)},
+                    "angle_trials_share_of_wave_time": round(s[18] / tot, 3), "shell_momentum_trials_share_of_wave_time": round(s[19] / tot, 3), "batches_with_an_S0_pass": round(s[6] / max(s[3], 1), 4), "open_tests_per_trial": round(s[7] / max(s[4], 1), 5)},
         "rayleigh": {"batches_per_history": round(s[8] / done, 4), "lanes_per_batch": r(s[9], s[8]), "share_of_wave_time": round(s[10] / tot, 3)},
         "tally_source": {"batches_per_history": round(s[11] / done, 4), "lanes_per_batch": r(s[12], s[11]), "share_of_wave_time": round(s[13] / tot, 3)},
         "exchange": {"per_history": round(s[14] / done, 4), "lanes_each": r(s[15], s[14]), "share_of_wave_time": round(s[16] / tot, 3)},
