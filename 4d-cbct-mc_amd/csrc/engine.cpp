@@ -214,6 +214,52 @@ void apply_schedule(DeviceModel& D) {
   HIP_TRY(hipMemcpy(D.cold, &ch, sizeof ch, hipMemcpyHostToDevice));
 }
 
+// COMPAT kernel: bounds of S0(E) = sum_i f_i n_i(E, theta = pi) (K.cu:1300-1314), the normalisation of the Compton angle test
+// "xi S0 > S(theta) T(tau)" (K.cu:1367-1372).  Computing it costs a second pass over the 29-40 electron shells of a tissue per
+// event -- 46 % of the kernel's Compton work -- and the test rarely needs its exact value.  S0 does not decrease with E: a
+// shell enters at E > U_i with a positive term, and each term grows with E (p_z(theta = pi) grows with E (E - U_i), the
+// profile integral n_i with p_z).  So S0 at the lower / upper edge of an energy bin bounds it inside the bin.  The edges are
+// evaluated here in double, one bin of slack on either side absorbs the float rounding of the kernel's bin index, and a
+// relative margin of 1e-4 covers the float arithmetic of the reference's own S0 (terms accurate to ~2e-6 of f_i, forty
+// additions of 6e-8 each).  A test that both bounds decide alike is decided; for the rest (well below 1 % with 1024 bins) the kernel computes S0.
+// Layout: float2 {lo, hi} at [row * kS0Bins + bin]; row = compact material index with `compact_of`, else material number - 1.
+static std::vector<float> build_s0_bounds(const HostModel& H, const int* compact_of, int rows, float* emin_out, float* inv_w_out) {
+  const double emin = H.mat.e0, emax = H.mat.e0 + (double)(H.mat.num_values - 1) / H.mat.ide, w = (emax - emin) / kS0Bins;
+  const double mc2 = (double)510998.918f, c1 = (double)0.707106781186545f, c2 = (double)1.4142135623731f;
+  std::vector<float> bounds((size_t)2 * kS0Bins * std::max(rows, 1), 0.f);
+  for (int m = 0; m < kMaxMaterials; ++m) {
+    const int mc = compact_of ? compact_of[m] : (m < rows ? m : -1);
+    if (mc < 0) continue;
+    const int n = std::min(H.mat.noscco[m], kMaxShells);
+    double fsum = 0.0;
+    for (int i = 0; i < n; ++i) fsum += (double)H.mat.fco[m + i * kMaxMaterials];
+    auto s0_at = [&](double E) {
+      double acc = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double U = H.mat.uico[m + i * kMaxMaterials], J = H.mat.fj0[m + i * kMaxMaterials], f = H.mat.fco[m + i * kMaxMaterials];
+        if (!(U < E)) continue;
+        const double aux = E * (E - U) * 2.0;
+        const double pz = J * (aux - U * mc2) / (std::sqrt(aux + aux + U * U) * mc2);
+        const double a = pz > 0.0 ? c1 + pz * c2 : c1 - pz * c2;
+        const double t = 0.5 * std::exp(0.5 - a * a);
+        acc += f * (pz > 0.0 ? 1.0 - t : t);
+      }
+      return acc;
+    };
+    std::vector<double> edge(kS0Bins + 1);
+    for (int k = 0; k <= kS0Bins; ++k) edge[k] = s0_at(emin + k * w);
+    for (int k = 0; k < kS0Bins; ++k) {
+      const double lo = k >= 1 ? edge[k - 1] * (1.0 - 1e-4) : 0.0;
+      const double hi = (k + 2 <= kS0Bins ? edge[k + 2] : fsum) * (1.0 + 1e-4);
+      bounds[2 * ((size_t)mc * kS0Bins + k)] = std::nextafterf((float)lo, -1.0f);
+      bounds[2 * ((size_t)mc * kS0Bins + k) + 1] = std::nextafterf((float)hi, 3.0e38f);
+    }
+  }
+  if (emin_out) *emin_out = (float)emin;
+  if (inv_w_out) *inv_w_out = (float)(1.0 / w);
+  return bounds;
+}
+
 // Build the palette-compressed volume and the compact-material tables and upload everything.
 void upload_model(mcgpu_ctx& C, int device_id) {
   const HostModel& H = C.host;
@@ -536,50 +582,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
   D.xco = D.put(xco); D.pco = D.put(pco); D.aco = D.put(aco); D.bco = D.put(bco);
   D.itl = D.put(itl); D.itu = D.put(itu);
   D.fco = D.put(fco); D.uico = D.put(uico); D.fj0 = D.put(fj0);
-  {
-    // COMPAT kernel: bounds of S0(E) = sum_i f_i n_i(E, theta = pi) (K.cu:1300-1314), the normalisation of the Compton angle test
-    // "xi S0 > S(theta) T(tau)" (K.cu:1367-1372).  Computing it costs a second pass over the 29-40 electron shells of a tissue per
-    // event -- 46 % of the kernel's Compton work -- and the test rarely needs its exact value.  S0 does not decrease with E: a
-    // shell enters at E > U_i with a positive term, and each term grows with E (p_z(theta = pi) grows with E (E - U_i), the
-    // profile integral n_i with p_z).  So S0 at the lower / upper edge of an energy bin bounds it inside the bin.  The edges are
-    // evaluated here in double, one bin of slack on either side absorbs the float rounding of the kernel's bin index, and a
-    // relative margin of 1e-4 covers the float arithmetic of the reference's own S0 (terms accurate to ~2e-6 of f_i, forty
-    // additions of 6e-8 each).  A test that both bounds decide alike is decided; for the rest (well below 1 % with 1024 bins) the kernel computes S0.
-    const double emin = H.mat.e0, emax = H.mat.e0 + (double)(H.mat.num_values - 1) / H.mat.ide, w = (emax - emin) / kS0Bins;
-    const double mc2 = (double)510998.918f, c1 = (double)0.707106781186545f, c2 = (double)1.4142135623731f;
-    std::vector<float> bounds((size_t)2 * kS0Bins * std::max(nmat, 1), 0.f);
-    for (int m = 0; m < kMaxMaterials; ++m) {
-      const int mc = D.compact_of[m];
-      if (mc < 0) continue;
-      const int n = std::min(H.mat.noscco[m], kMaxShells);
-      double fsum = 0.0;
-      for (int i = 0; i < n; ++i) fsum += (double)H.mat.fco[m + i * kMaxMaterials];
-      auto s0_at = [&](double E) {
-        double acc = 0.0;
-        for (int i = 0; i < n; ++i) {
-          const double U = H.mat.uico[m + i * kMaxMaterials], J = H.mat.fj0[m + i * kMaxMaterials], f = H.mat.fco[m + i * kMaxMaterials];
-          if (!(U < E)) continue;
-          const double aux = E * (E - U) * 2.0;
-          const double pz = J * (aux - U * mc2) / (std::sqrt(aux + aux + U * U) * mc2);
-          const double a = pz > 0.0 ? c1 + pz * c2 : c1 - pz * c2;
-          const double t = 0.5 * std::exp(0.5 - a * a);
-          acc += f * (pz > 0.0 ? 1.0 - t : t);
-        }
-        return acc;
-      };
-      std::vector<double> edge(kS0Bins + 1);
-      for (int k = 0; k <= kS0Bins; ++k) edge[k] = s0_at(emin + k * w);
-      for (int k = 0; k < kS0Bins; ++k) {
-        const double lo = k >= 1 ? edge[k - 1] * (1.0 - 1e-4) : 0.0;
-        const double hi = (k + 2 <= kS0Bins ? edge[k + 2] : fsum) * (1.0 + 1e-4);
-        bounds[2 * ((size_t)mc * kS0Bins + k)] = std::nextafterf((float)lo, -1.0f);
-        bounds[2 * ((size_t)mc * kS0Bins + k) + 1] = std::nextafterf((float)hi, 3.0e38f);
-      }
-    }
-    D.s0_bounds = D.put(bounds);
-    D.s0_emin = (float)emin;
-    D.s0_inv_w = (float)(1.0 / w);
-  }
+  D.s0_bounds = D.put(build_s0_bounds(H, D.compact_of, nmat, &D.s0_emin, &D.s0_inv_w));  // COMPAT: bounds of S0 per (material, energy bin)
   D.noscco = D.put(nosc);
   D.shell_cut = D.put(shell_cut);
   D.shell_alias = D.put(shell_alias);
@@ -821,6 +824,13 @@ const void* host_table(mcgpu_ctx& C, const std::string& name, size_t& bytes) {
   if (name == "uico") DIRECT(H.mat.uico);
   if (name == "fj0") DIRECT(H.mat.fj0);
 #undef DIRECT
+  if (name == "s0_bounds") {  // COMPAT kernel: {lo, hi} of S0 per (material number - 1, energy bin), then {emin, 1 / bin width}
+    float emin = 0.f, inv_w = 0.f;
+    std::vector<float> b = build_s0_bounds(H, nullptr, kMaxMaterials, &emin, &inv_w);
+    b.push_back(emin);
+    b.push_back(inv_w);
+    return cache(b.data(), b.size() * sizeof(float));
+  }
   if (name == "noscco") return cache(H.mat.noscco, sizeof H.mat.noscco);
   if (name == "espc") return cache(H.spectrum.espc, sizeof H.spectrum.espc);
   if (name == "espc_cutoff") return cache(H.spectrum.cutoff, sizeof H.spectrum.cutoff);

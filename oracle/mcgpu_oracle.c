@@ -514,6 +514,27 @@ static void gcoa(const oracle_tables *T, float *energy, double *costh, int mat, 
     *energy = E * t;
   }
 }
+/* S(E, theta) = sum_i f_i n_i(E, theta) in the reference's float arithmetic (K.cu:1300-1314 for cdt = 2, i.e. S0; :1340-1366 for
+ * the angle of a trial): what the product's COMPAT kernel brackets with its S0 bounds (tests/test_host_tables.py) */
+float oracle_compton_s(const oracle_tables *T, float E, float cdt, int mat, int math_mode)
+{
+  float s = 0.0f;
+  for (int i = 0; i < T->noscco[mat]; i++) {
+    float t = T->uico[mat + i * MAXMAT];
+    if (t < E) {
+      float aux = E * (E - t) * cdt, pz;
+      if ((aux > 1.0e-12f) || (t > 1.0e-12f)) pz = shell_pz(T->fj0[mat + i * MAXMAT], aux, t);
+      else pz = 0.002f;
+      t = pz * 1.4142135623731f;
+      if (pz > 0.0f) t = 0.5f - (t + 0.70710678118654502f) * (t + 0.70710678118654502f);
+      else t = 0.5f - (0.70710678118654502f - t) * (0.70710678118654502f - t);
+      t = 0.5f * m_expf(t, math_mode);
+      if (pz > 0.0f) t = 1.0f - t;
+      s += T->fco[mat + i * MAXMAT] * t;
+    }
+  }
+  return s;
+}
 void oracle_gcoa(const oracle_tables *T, float *energy, double *costh, int mat, int *seed2, int math_mode)
 { i2 s = { seed2[0], seed2[1] }; uint64_t c = 0; gcoa(T, energy, costh, mat, &s, math_mode, &c); seed2[0] = s.x; seed2[1] = s.y; }
 void oracle_source(const oracle_tables *T, int num_p, int *seed2, float *pos3, float *dir3, float *energy, int *absvox, int math_mode)

@@ -75,6 +75,8 @@ def oracle():
         lib.oracle_pm_log.argtypes = [C.c_double]
         lib.oracle_pm_exp.restype = C.c_double
         lib.oracle_pm_exp.argtypes = [C.c_double]
+        lib.oracle_compton_s.restype = C.c_float
+        lib.oracle_compton_s.argtypes = [C.POINTER(OracleTables), C.c_float, C.c_float, C.c_int, C.c_int]
         lib.oracle_gl_expf.restype = C.c_float
         lib.oracle_gl_expf.argtypes = [C.c_float]
         lib.oracle_pm_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -118,3 +118,40 @@ def test_bench_size_cirs_tables_equal_the_reference_parse(engine, tmp_path):
     pin = gu.fullsize_pin("cirs")
     assert used == pin["used_materials"]
     assert got == pin["sha256"]
+
+
+def test_s0_bounds_bracket_the_reference_arithmetic(engine, case_dir):
+    """The COMPAT kernel decides the Compton angle test from bounds lo <= S0 <= hi (engine.cpp: build_s0_bounds) and rejects
+    without a pass over the shells when xi lo > hi T(tau), which also needs S(theta) <= hi.  Both facts are held here against
+    the reference's own float arithmetic (the oracle's, libm and portable math) for every material: at random energies, at the
+    energies next to every bin edge, and for random deflections; the smallest slack is reported with the assertion."""
+    import ctypes as C
+    import oracle_lib as ol
+    import parity
+    with engine.create(case_dir("tissue22"), device=-1) as ctx:
+        T = parity.tables_from_context(ctx)
+        raw = ctx.host_table("s0_bounds", "<f4")
+        nb = (raw.size - 2) // (2 * 25)
+        emin, inv_w = float(raw[-2]), float(raw[-1])
+        b = raw[:-2].reshape(25, nb, 2)
+        nosc = ctx.host_table("noscco", "<i4")
+        e_hi = float(np.float32(ctx.getf("e0"))) + (ctx.geti("num_energy_values") - 1) / float(np.float32(ctx.getf("ide")))
+        lib = ol.oracle()
+        rng = np.random.default_rng(17)
+        worst = 1.0
+        for mat in [m for m in range(25) if nosc[m] > 0]:
+            edges = emin + np.arange(0, nb + 1, 37) / inv_w
+            energies = np.concatenate([rng.uniform(emin, e_hi, 400), edges, np.nextafter(edges.astype(np.float32), np.float32(0)),
+                                       np.nextafter(edges.astype(np.float32), np.float32(1e9)), [emin, e_hi]]).astype(np.float32)
+            energies = energies[(energies >= np.float32(emin)) & (energies <= np.float32(e_hi))]
+            for E in energies:
+                k = min(max(int(np.float32(np.float32(E - np.float32(emin)) * np.float32(inv_w))), 0), nb - 1)  # the kernel's bin
+                lo, hi = float(b[mat, k, 0]), float(b[mat, k, 1])
+                for mode in (ol.MATH_LIBM, ol.MATH_PORTABLE):
+                    s0 = float(lib.oracle_compton_s(C.byref(T.ct), float(E), 2.0, mat, mode))
+                    assert lo <= s0 <= hi, (mat, float(E), lo, s0, hi)
+                    worst = min(worst, (s0 - lo) / max(s0, 1e-30) if lo > 0 else 1.0, (hi - s0) / max(s0, 1e-30))
+                    cdt = float(np.float32(rng.uniform(0.0, 2.0)))
+                    assert float(lib.oracle_compton_s(C.byref(T.ct), float(E), cdt, mat, mode)) <= hi, (mat, float(E), cdt)
+        print("smallest relative slack of the S0 bounds:", worst)
+        assert worst > 2e-5, worst  # the margin of 1e-4 is not eaten by the float arithmetic
