@@ -246,6 +246,18 @@ static std::vector<float> build_s0_bounds(const HostModel& H, const int* compact
       }
       return acc;
     };
+    // the monotonicity argument needs shells with f >= 0, J > 0, U >= 0 (every PENELOPE table has them); a file that breaks it
+    // gets bounds that decide nothing: the kernel then computes S0 for every test, like the reference
+    bool regular = true;
+    for (int i = 0; i < n; ++i)
+      regular = regular && H.mat.fco[m + i * kMaxMaterials] >= 0.f && H.mat.fj0[m + i * kMaxMaterials] > 0.f && H.mat.uico[m + i * kMaxMaterials] >= 0.f;
+    if (!regular) {
+      for (int k = 0; k < kS0Bins; ++k) {
+        bounds[2 * ((size_t)mc * kS0Bins + k)] = 0.f;
+        bounds[2 * ((size_t)mc * kS0Bins + k) + 1] = 3.0e38f;
+      }
+      continue;
+    }
     std::vector<double> edge(kS0Bins + 1);
     for (int k = 0; k <= kS0Bins; ++k) edge[k] = s0_at(emin + k * w);
     for (int k = 0; k < kS0Bins; ++k) {
