@@ -764,16 +764,16 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   // the sweep (profiles/r03u_compat_sweep.txt): thorax 4.1e8, CIRS 9.2e8, Catphan 1.8e9; exchanging the two histories of a lane
   // pays from 1-8 takers on (thresh_take), 16+ loses.
   // Later in round 3 the Compton batch lost two thirds of its cost (S0 bounds, in-place Klein-Nishina rejections) and the wave takes
-  // four flight steps between two looks at its state: 48 / 4 / 16 on tissue and 32 / 4 / 24 on plastics sit on flat optima
+  // four flight steps between two looks at its state: 48 / 8 / 16 on tissue and 32 / 4 / 24 on plastics sit on flat optima
   // (profiles/r03y_compat_sweep.txt).
   int shells = 0, used = 0;
   for (int m = 0; m < kMaxMaterials; ++m)
     if (D.compact_of[m] >= 0) { shells += std::min(H.mat.noscco[m], kMaxShells); ++used; }
   const bool many_shells = used > 0 && shells >= 20 * used;
   A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 48 : 32);
-  A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : 4;
+  A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : (many_shells ? 8 : 4);
   A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 16 : 24);
-  A.thresh_take = D.knobs.compat_thresh[3] >= 0 ? D.knobs.compat_thresh[3] : 4;
+  A.thresh_take = D.knobs.compat_thresh[3] >= 0 ? D.knobs.compat_thresh[3] : 2;
   return A;
 }
 
