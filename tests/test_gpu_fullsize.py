@@ -211,3 +211,40 @@ def test_bench_size_host_tables_equal_the_reference_parse(workload, request):
     pin = gu.fullsize_pin(workload)
     assert used == pin["used_materials"]
     assert got == pin["sha256"], {k: (got[k][:12], pin["sha256"][k][:12]) for k in got if got[k] != pin["sha256"][k]}
+
+
+@pytest.mark.parametrize("workload,p", [("catphan", 447), ("cirs", 300), ("thorax", 600)])
+def test_fast_against_the_bit_exact_personality_with_4e9_histories(workload, p, request):
+    """The COMPAT kernel (bit-identical to the oracle, 1-3e9 histories/s) as the yardstick of the statistical personality:
+    16 independent runs of 2.5e8 histories per mode, variances from the run-to-run scatter.  Detected energy per history per
+    scatter class within 4 sigma (sigma ~ 2e-5 for the primary, ~ 4e-4 for the scatter classes), the z of the 32x32-pixel
+    blocks with unit variance.  The block column of the primary beam's edge (detector column 1024, the reference's own crop,
+    proj.py:42-51) is left out: the 2e-8 of the primary energy that lands within a hundredth of a pixel of it falls to
+    either side depending on the last bits of the direction (profiles/r03z_fast_vs_compat.txt)."""
+    ctx = request.getfixturevalue({"catphan": "catphan512", "thorax": "thorax512", "cirs": "cirs_full"}[workload])
+    K, n, B = 16, 250_000_000, 32
+    batches, hpt, _ = ctx.reference_shape(n)
+
+    def blocks(img):
+        c, nz, nx = img.shape
+        return img[:, :nz // B * B, :nx // B * B].reshape(c, nz // B, B, nx // B, B).sum(axis=(2, 4)).astype(np.float64)
+
+    F, Cc = [], []
+    for k in range(K):
+        img, _, d = ctx.run_projection(p, n, mode="fast", seed=4000 + k)
+        F.append(blocks(img) / d)
+        img, _, d = ctx.run_projection(p, batches, mode="compat", seed=6000 + 7 * k, hpt=hpt)
+        Cc.append(blocks(img) / d)
+    F, Cc = np.array(F), np.array(Cc)
+    F[:, 0, :, 1024 // B] = 0.0
+    Cc[:, 0, :, 1024 // B] = 0.0
+    ef, ec = F.sum(axis=(2, 3)), Cc.sum(axis=(2, 3))
+    for c in range(4):
+        se = np.sqrt(ef[:, c].var(ddof=1) / K + ec[:, c].var(ddof=1) / K)
+        z = (ef[:, c].mean() - ec[:, c].mean()) / se
+        assert abs(z) < 4.0, (workload, c, z, ef[:, c].mean() / ec[:, c].mean())
+    se = np.sqrt(F.var(axis=0, ddof=1) / K + Cc.var(axis=0, ddof=1) / K)
+    for c in range(4):
+        m = (Cc.mean(axis=0)[c] > 0) & (se[c] > 0)
+        z = (F.mean(axis=0)[c][m] - Cc.mean(axis=0)[c][m]) / se[c][m]
+        assert z.size > 500 and abs(z.mean()) < 0.3 and 0.9 < z.std() < 1.2 and (np.abs(z) > 6.5).sum() == 0, (workload, c, z.mean(), z.std(), np.abs(z).max())  # Student t with 30 degrees of freedom: heavy tails
