@@ -189,6 +189,27 @@ def compat_leg(ctx, torch, H, launches=3):
             "what": "COMPAT kernel: RANECU streams + reference arithmetic, tallies bit-identical to the CPU oracle (tests/test_gpu_fullsize.py)"}
 
 
+def fast_vs_compat_check(ctx, runs=12, histories=250_000_000, projection=447):
+    """FAST against the bit-exact COMPAT personality (tallies bit-identical to the oracle, tests/test_gpu_parity.py): `runs`
+    independent launches of `histories` per mode, variances from the run-to-run scatter.  Detected energy per history per
+    scatter class: ratio, relative sigma, z.  (tools/fast_vs_compat.py is the long version)"""
+    p = projection % ctx.num_projections
+    batches, hpt, _ = ctx.reference_shape(histories)
+    ef, ec = [], []
+    for k in range(runs):
+        img, _, d = ctx.run_projection(p, histories, mode="fast", seed=8000 + k)
+        ef.append(img.reshape(4, -1).sum(axis=1, dtype=np.float64) / d)
+        img, _, d = ctx.run_projection(p, batches, mode="compat", seed=9000 + 7 * k, hpt=hpt)
+        ec.append(img.reshape(4, -1).sum(axis=1, dtype=np.float64) / d)
+    ef, ec = np.array(ef), np.array(ec)
+    se = np.sqrt(ef.var(axis=0, ddof=1) / runs + ec.var(axis=0, ddof=1) / runs)
+    z = (ef.mean(axis=0) - ec.mean(axis=0)) / np.where(se > 0, se, 1.0)
+    return {"projection": int(p), "runs_per_mode": runs, "histories_per_run": int(histories), "classes": ["primary", "compton", "rayleigh", "multiple"],
+            "energy_ratio_fast_over_compat": [float(a / b) if b else None for a, b in zip(ef.mean(axis=0), ec.mean(axis=0))],
+            "relative_sigma": [float(a / b) if b else None for a, b in zip(se, ec.mean(axis=0))],
+            "energy_z": [round(float(v), 3) for v in z], "passed": bool(np.all(np.abs(z) < 6.0))}  # Student t with 2 runs - 2 = 22 degrees of freedom: P(|t| > 6) = 5e-6 per class
+
+
 def oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu):
     """FAST vs the oracle sample of cpu_baseline on projection 0: detected energy per history per scatter class (ratio and
     z with the oracle's measured variance) and 16x16-pixel blocks."""
@@ -661,6 +682,8 @@ def main():
         if world == 1:
             if not args.no_compat:
                 out["compat"] = compat_leg(ctx, torch, H)
+                out["check"]["fast_vs_compat"] = fast_vs_compat_check(ctx)
+                failed = failed or not out["check"]["fast_vs_compat"]["passed"]
             if not args.no_end_to_end:
                 out["end_to_end"] = end_to_end_scan(ctx, H, workdir, n=min(args.scan_projections, nproj))
                 if args.ascii_projections > 0:
@@ -677,6 +700,7 @@ def main():
                                       "unit": "Gatomic/s", "frac": tally_hits * H / (k_ms * 1e-3) / 23.7e9,
                                       "detected_photons_per_history": tally_hits}
             out["check"].update(oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu))
+            out["check"]["passed"] = bool(out["check"]["passed"] and out["check"].get("fast_vs_compat", {}).get("passed", True))
             failed = failed or not out["check"]["passed"]
         else:
             out["cpu_baseline"] = None
