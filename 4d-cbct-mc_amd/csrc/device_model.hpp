@@ -45,7 +45,7 @@ constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgrou
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)
-constexpr int kSlotWords = 14;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
+constexpr int kSlotWords = 12;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kS0Bins = 1024;            // COMPAT: energy bins of the S0 bounds (TrackCold::s0_bounds)
 constexpr int kNumStats = 32;             // scheduler counters of the diagnostic build
 constexpr int kWaveTrace = 16384;         // diagnostic build: {hardware id, first and last clock} of up to this many waves follow the counters

@@ -28,7 +28,7 @@ typedef struct mcgpu_ctx mcgpu_ctx;
 
 /* Kernel personalities.
  * FAST   : production path -- counter-based per-history RNG streams (Philox4x32-7 seeding a
- *          xoshiro128+ lane generator), gfx950 native transcendental instructions, exactly
+ *          multiply-with-carry lane generator), gfx950 native transcendental instructions, exactly
  *          n_histories histories; statistically equivalent to the reference (3-sigma per pixel).
  * COMPAT : RANECU leap-frog streams (batch <-> thread mapping of MC-GPU_kernel_v1.3.cu:198,841-894),
  *          the reference CPU-build arithmetic and the portable math of oracle/mcgpu_oracle.c;
