@@ -364,7 +364,7 @@ def cases_root():
 
 
 def test_fast_kernel_history_ids_beyond_32_bits(gpu_engine, case_dir):
-    """BASELINE config 3 asks for 1.19e10 histories per projection: history ids (the Philox counter), id ranges of a rank and
+    """BASELINE config 3 asks for 1.19e10 histories per projection: history ids (the counter the per-history seeding hashes), id ranges of a rank and
     the launch size itself pass 2^32.  A range that straddles 2^32 equals the sum of its two halves; a 5e9-history launch
     simulates exactly that many and agrees with 50 x a 1e8-history launch within the statistics of the latter."""
     with gpu_engine.create(case_dir("water"), device=0) as ctx:
