@@ -217,7 +217,7 @@ def test_bench_size_host_tables_equal_the_reference_parse(workload, request):
 def test_fast_against_the_bit_exact_personality_with_4e9_histories(workload, p, request):
     """The COMPAT kernel (bit-identical to the oracle, 1-3e9 histories/s) as the yardstick of the statistical personality:
     16 independent runs of 2.5e8 histories per mode, variances from the run-to-run scatter.  Detected energy per history per
-    scatter class within 4 sigma (sigma ~ 2e-5 for the primary, ~ 4e-4 for the scatter classes), the z of the 32x32-pixel
+    scatter class within 5 sigma (sigma ~ 2e-5 for the primary, ~ 4e-4 for the scatter classes), the z of the 32x32-pixel
     blocks with unit variance.  The block column of the primary beam's edge (detector column 1024, the reference's own crop,
     proj.py:42-51) is left out: the 2e-8 of the primary energy that lands within a hundredth of a pixel of it falls to
     either side depending on the last bits of the direction (profiles/r03z_fast_vs_compat.txt)."""
@@ -242,7 +242,7 @@ def test_fast_against_the_bit_exact_personality_with_4e9_histories(workload, p, 
     for c in range(4):
         se = np.sqrt(ef[:, c].var(ddof=1) / K + ec[:, c].var(ddof=1) / K)
         z = (ef[:, c].mean() - ec[:, c].mean()) / se
-        assert abs(z) < 4.0, (workload, c, z, ef[:, c].mean() / ec[:, c].mean())
+        assert abs(z) < 5.0, (workload, c, z, ef[:, c].mean() / ec[:, c].mean())  # Student t, 30 degrees of freedom: P(|t| > 5) = 2e-5
     se = np.sqrt(F.var(axis=0, ddof=1) / K + Cc.var(axis=0, ddof=1) / K)
     for c in range(4):
         m = (Cc.mean(axis=0)[c] > 0) & (se[c] > 0)
