@@ -492,6 +492,25 @@ def main():
         ok, err = cases.pkg.sharding.connect_exchange(x, dist)  # the same verdict on every rank
         if rank == 0:
             shm.unlink(missing_ok=True)  # every rank holds its mapping
+        first_step = 0
+        if ok:
+            # dry run of the whole protocol on empty tallies, both buffer parities: copy-engine pushes into IPC memory of ANOTHER
+            # device, stream waits on interprocess events, the fused add -- everything a real step does except the tracking kernel.
+            # A node on which any of that fails between two devices falls back to RCCL with all ranks, here, not in the timed region.
+            try:
+                for k in (0, 1):
+                    x.begin(k, stream)
+                    x.submit(k, stream)
+                for k in (0, 1):
+                    x.collect(k, stream)
+                torch.cuda.synchronize()
+                dry = None
+            except Exception as e:  # noqa: BLE001 -- reported, and agreed on below
+                dry = e
+            flags = [None] * world
+            dist.all_gather_object(flags, dry is None)
+            ok, err = all(flags), (dry or err)
+            first_step = 2
         if not ok:
             # no IPC between these ranks' devices (or the runtime refused an interprocess event): every rank falls back to the
             # RCCL reduction together -- slower (the collective is exposed between kernels), but a measurement instead of a failure
@@ -509,7 +528,7 @@ def main():
     reduce_algo = os.environ.get("BENCH_REDUCE_ALGO", "scatter")
     reduce_bytes = [0]
     last_reduced = [None]  # device pointer / tensor of the last complete tally this rank holds
-    n_step = [0]           # exchange step counter (consecutive over warm-up, timed region and the check)
+    n_step = [first_step if x else 0]  # exchange step counter (consecutive over the dry run, warm-up, timed region and the check)
 
     def reduce_group():
         if exchange_kind == "rccl" and filled[0] > 0:
@@ -517,7 +536,7 @@ def main():
             reduce_bytes[0] += cases.pkg.sharding.reduce_image(images[:filled[0]], dst=0, narrow=narrow, algorithm=reduce_algo)
         filled[0] = 0
 
-    collected = [0]        # exchange steps collected so far (each step is collected exactly once, in order)
+    collected = [first_step if x else 0]  # exchange steps collected so far (each step is collected exactly once, in order)
 
     def collect_up_to(k_excl):
         while x and collected[0] < k_excl:
