@@ -27,6 +27,8 @@ hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stre
 int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
+hipError_t launch_kat_streams_fast(int generator, unsigned int seed, unsigned int stream_key, unsigned long long first_id,
+                                   const unsigned long long* ids_dev, int n_ids, int n_draws, unsigned int* out_dev, hipStream_t stream);
 hipError_t launch_kat_math(int n, const double* x, double* l, double* e, double* s, double* c, hipStream_t stream);
 hipError_t launch_kat_expf(int n, const float* x, float* e, hipStream_t stream);
 hipError_t launch_kat_f32(int op, int n, const float* a, const float* b, float* out, hipStream_t stream);
@@ -1639,6 +1641,31 @@ int mcgpu_kat_rng(mcgpu_ctx* ctx, int mode, int seed, int batch, int hpt, int n,
   hipError_t e = launch_kat_rng(mode, seed, batch, hpt, n, d, nullptr);
   if (e == hipSuccess) e = hipMemcpy(out_f32, d, (size_t)n * 4, hipMemcpyDeviceToHost);
   (void)hipFree(d);
+  HIP_TRY(e);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_kat_rng_streams(mcgpu_ctx* ctx, int generator, unsigned int seed, unsigned int projection, unsigned long long first_id,
+                          const unsigned long long* ids, int n_ids, int n_draws, uint32_t* out_u32) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && out_u32 && n_ids > 0 && n_draws > 0 && (generator == 0 || generator == 1) &&
+              (size_t)n_ids * (size_t)n_draws <= ((size_t)1 << 30),
+          -1, "!!ERROR!! mcgpu_kat_rng_streams: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  unsigned int* d = nullptr;
+  unsigned long long* d_ids = nullptr;
+  const size_t nb = (size_t)n_ids * (size_t)n_draws * 4;
+  HIP_TRY(hipMalloc((void**)&d, nb));
+  hipError_t e = hipSuccess;
+  if (ids) {
+    e = hipMalloc((void**)&d_ids, (size_t)n_ids * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_ids, ids, (size_t)n_ids * 8, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = launch_kat_streams_fast(generator, seed, projection, first_id, d_ids, n_ids, n_draws, d, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out_u32, d, nb, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (d_ids) (void)hipFree(d_ids);
   HIP_TRY(e);
   return 0;
   ABI_END

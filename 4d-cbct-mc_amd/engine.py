@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
-    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
     "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
     "mcgpu_exchange_connect_local", "mcgpu_exchange_probe", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
     "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
@@ -117,6 +117,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
     lib.mcgpu_write_voxel_binary.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+    lib.mcgpu_kat_rng_streams.argtypes = [vp, ci, C.c_uint, C.c_uint, C.c_ulonglong, vp, ci, ci, vp]
     lib.mcgpu_reload_env_knobs.argtypes = [vp]
     lib.mcgpu_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.mcgpu_exchange_shared_bytes.argtypes = [ci]
@@ -597,6 +598,16 @@ class Context:
     def kat_rng(self, mode, seed: int, batch: int, hpt: int, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.float32)
         _check(self.lib.mcgpu_kat_rng(self.h, _MODES[mode], seed, batch, hpt, n, out.ctypes.data))
+        return out
+
+    def kat_rng_streams(self, seed: int, projection: int, n_draws: int, first_id: int = 0, n_ids: int = 0, ids=None, generator: int = 0) -> np.ndarray:
+        """uint32[n_ids, n_draws]: raw outputs of the FAST per-history streams (generator 1: the Philox-per-draw yardstick)."""
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.uint64)
+            n_ids = ids.size
+        out = np.zeros((n_ids, n_draws), dtype=np.uint32)
+        _check(self.lib.mcgpu_kat_rng_streams(self.h, generator, seed, projection, first_id, ids.ctypes.data if ids is not None else None,
+                                              n_ids, n_draws, out.ctypes.data))
         return out
 
     def kat_math(self, x: Sequence[float]):

@@ -293,6 +293,12 @@ int mcgpu_write_voxel_binary(const char *path, const int n[3], const float spaci
 
 /* Device-side known-answer hooks used by the parity tests (each runs a tiny kernel on the context's device). */
 int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n, float *out_f32);
+/* Raw 32-bit outputs of the FAST personality's per-history streams (no reference counterpart: the reference's RANECU,
+ * MC-GPU_kernel_v1.3.cu:841-894, is the COMPAT personality's).  out_u32[i * n_draws + k] = k-th output of the stream of history
+ * ids[i] (ids == NULL: first_id + i) at projection `projection`.  generator 0 = production (Philox4x32-7 seeds a multiply-with-
+ * carry lane generator; restated in oracle/fast_rng.py), 1 = Philox4x32-10 per draw (the yardstick of the statistical tests). */
+int mcgpu_kat_rng_streams(mcgpu_ctx *ctx, int generator, unsigned int seed, unsigned int projection, unsigned long long first_id,
+                          const unsigned long long *ids, int n_ids, int n_draws, uint32_t *out_u32);
 int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, double *out_exp, double *out_sin, double *out_cos);
 /* expf as the COMPAT kernel evaluates it (the C library's single-precision algorithm, track_common.inc gl_expf) */
 int mcgpu_kat_expf(mcgpu_ctx *ctx, int n, const float *x, float *out_exp);
