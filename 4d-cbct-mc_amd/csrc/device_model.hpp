@@ -43,6 +43,8 @@ inline unsigned int tiled_voxel(unsigned int ix, unsigned int iy, unsigned int i
 }
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
+constexpr int kPoolParked = 1;            // FAST kernel: histories a lane parks in LDS slots beside the one in its registers
+constexpr int kPoolWavesPerSimd = 2 * kPoolBlockThreads / 64 / 4;  // two workgroups per CU (each gets half of the 160 KB of LDS)
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)
 constexpr int kSlotWords = 12;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
@@ -60,7 +62,7 @@ struct LdsLayout {
   int pal;                   // float2[16 + palette_size]: brick-code entries, then the palette (u8 volumes)
   int brick;                 // u8[brick_bytes]
   int dose_mat;              // u64[25][2]: per-workgroup material-dose accumulators, flushed at kernel end
-  int slots;                 // u32[kSlotWords][kPoolBlockThreads] (FAST kernel only)
+  int slots;                 // u32[kSlotWords][kPoolParked * kPoolBlockThreads] (FAST kernel only)
   // FAST kernel only: brackets of the total cross section per (coarse energy bin, material), TrackArgs::sig_shift >= 0
   int sig_mid;               // fp16[ncoarse * nmat]: centre of [min, max] of mfp_tot over the coarse bin
   int sig_w;                 // float[ncoarse]: relative half width that covers every material of the bin

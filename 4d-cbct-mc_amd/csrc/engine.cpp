@@ -396,7 +396,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       const int ns = std::min(H.spectrum.num_bins + 1, kMaxSpectrumBins) + 1;
       const int nc = (nv + (1 << 9) - 1) >> 9;  // brackets no coarser than 2^9 table bins
       const long fixed = std::max(shells, 1) * 16 + std::max(nmat, 1) * 8 + ns * 10 + (16 + (long)index_of.size()) * 8 + 2 * kMaxMaterials * 8 +
-                         (long)kSlotWords * kPoolBlockThreads * 4 + nc * nmat * 2 + nc * 4 + 12 * 16;
+                         (long)kSlotWords * kPoolParked * kPoolBlockThreads * 4 + nc * nmat * 2 + nc * 4 + 12 * 16;
       const long left = 160 * 1024 / 2 - fixed;
       if (left > 0) max_bricks = std::min(max_bricks, std::max(2 * left, 512L));
     }
@@ -621,7 +621,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.brick = take(D.vol_kind == kVolU8 ? D.brick_bytes : 0, 16);
     Y.dose_mat = take(2 * kMaxMaterials * 8, 16);
     Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
-    take(kSlotWords * kPoolBlockThreads * 4, 16);
+    take(kSlotWords * kPoolParked * kPoolBlockThreads * 4, 16);
     Y.sig_mid = Y.sig_w = off;
     D.sig_shift = -1;
     if (!getenv("MCGPU_NO_BRACKETS") && nmat > 0) {

@@ -9,6 +9,9 @@
 //                        pushes to the projection's owner device, one fused add; integers: order-independent)
 //   --devices a,b,...    the same with an explicit device list (a device may appear twice: used by the tests to run the
 //                        sharded path on a single-GPU box)
+//   --shard histories|projections   with several devices: share every projection's histories (default: the reference's split,
+//                        tallies summed through the exchange) or give every device whole projections (no traffic between the
+//                        devices at all: the fallback for nodes without working peer access; same output bytes)
 //   --no-output          skip the ASCII projection files (timing runs, or stacks only)
 //   --stacks             also write projections_{total,unscattered,scattered}.mha next to the projection files
 //                        (what cbctmc/mc/simulation.py:235-277 builds from the ASCII files afterwards)
@@ -34,7 +37,7 @@ int main(int argc, char** argv) {
     printf("\n\n   !!read_input ERROR!! Input file name not given as an execution parameter!! Try again...\n\n");
     return 255;
   }
-  int mode = MCGPU_MODE_FAST, ngpu = 1;
+  int mode = MCGPU_MODE_FAST, ngpu = 1, shard = MCGPU_SHARD_HISTORIES;
   bool write_out = true, stacks = false;
   int crop = -1;
   const char* air = nullptr;
@@ -51,6 +54,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--air") && i + 1 < argc) air = argv[++i];
     else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = !strcmp(argv[++i], "compat") ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--shard") && i + 1 < argc) shard = !strcmp(argv[++i], "projections") ? MCGPU_SHARD_PROJECTIONS : MCGPU_SHARD_HISTORIES;
     else if (!strcmp(argv[i], "--no-output")) write_out = false;
   }
   if (!device_list.empty()) ngpu = (int)device_list.size();
@@ -90,6 +94,7 @@ int main(int argc, char** argv) {
   memset(&so, 0, sizeof so);
   so.mode = mode;
   so.progress = 1;
+  so.shard = shard;
   so.crop_nx = (crop > 0 && crop < det_nx) ? crop : (int)det_nx;
   so.write_ascii = write_out ? 1 : 0;
   so.write_stacks = stacks ? 1 : 0;

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -63,6 +64,7 @@ struct MhaStack {
   std::vector<uint64_t> zeros;  // element indices of the exact zeros of slices that hold only a few (patched in place by finish)
   std::vector<uint32_t> zero_count;  // exact zeros per slice (a slice with many is rewritten whole by finish)
   std::vector<unsigned char> have;  // slices written so far (random-access writes of a 4-D scan)
+  std::mutex mu;                    // writes by slice index may come from several scans at once (projection-sharded devices)
 };
 
 static std::string fmt_g(double v) {
@@ -119,6 +121,7 @@ static void note_zeros(MhaStack* s, int k, const float* plane) {
 
 // Write slice k (any order, each slice once): a 4-D scan visits the projections grouped by respiratory state.
 void mha_write_slice(MhaStack* s, int k, const float* plane) {
+  std::lock_guard<std::mutex> lk(s->mu);
   if (k < 0 || k >= s->nslices) throw Error(-3, "!!ERROR!! slice index outside " + s->path);
   if (s->have.empty()) s->have.assign((size_t)s->nslices, 0);
   if (s->have[k]) throw Error(-3, "!!ERROR!! slice written twice in " + s->path);

@@ -73,8 +73,10 @@ struct DeviceLane {  // per device
 
 extern "C" void mcgpu_set_last_error_(const char* message);  // engine.cpp (not part of the public ABI)
 
-extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
-  if (!ctxs || n_ctx < 1 || !opt || !ctxs[0]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
+namespace {
+
+// One scan over n_ctx devices that share every projection's histories (n_ctx = 1: the plain single-device pipeline).
+int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
   std::vector<DeviceLane> D((size_t)n_ctx);
   float* planes_host[2] = {nullptr, nullptr};
   uint64_t* image_host[2] = {nullptr, nullptr};
@@ -133,9 +135,20 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     ABI_OK(mcgpu_config_f64(ctx, "angularROI_0", &roi0));
     ABI_OK(mcgpu_config_f64(ctx, "angularROI_1", &roi1));
     auto outside_roi = [&](int p) { const double a = angle0 + p * d_angle; return a < roi0 || a > roi1; };
-    std::vector<int> sim;  // offsets within the range of the projections that are simulated
-    for (int k = 0; k < range; ++k)
-      if (!outside_roi(first + k)) sim.push_back(k);
+    // offsets within the range of the projections this scan simulates, and their ordinal among ALL simulated projections of the
+    // range (a projection-sharded scan takes every stride-th of them: the COMPAT seed still moves on once per simulated
+    // projection, whoever simulates it)
+    const int stride = opt->projection_stride > 1 ? opt->projection_stride : 1, phase = stride > 1 ? opt->projection_phase : 0;
+    if (phase < 0 || phase >= stride) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection_phase outside [0, projection_stride)"};
+    std::vector<int> sim, ord;
+    {
+      int n_sim = 0;
+      for (int k = 0; k < range; ++k)
+        if (!outside_roi(first + k)) {
+          if (n_sim % stride == phase) { sim.push_back(k); ord.push_back(n_sim); }
+          ++n_sim;
+        }
+    }
     const int count = (int)sim.size();
     unsigned long long H = opt->histories_per_projection ? opt->histories_per_projection : (unsigned long long)hist_in;
     // An input value below 95000 is a time budget in seconds per projection, not a history count (MC-GPU_v1.3.cu:650-655,
@@ -346,9 +359,11 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     const double t0 = now_s();
     double kernel_s = 0.0, t_last_kernel = t0;
     int cur_seed = (int)seed;
-    if (mode == MCGPU_MODE_COMPAT)  // the seed moves on per SIMULATED projection (MC-GPU_v1.3.cu:869)
+    if (mode == MCGPU_MODE_COMPAT) {  // the seed moves on per SIMULATED projection (MC-GPU_v1.3.cu:869)
       for (int p = 0; p < first; ++p)
         if (!outside_roi(p)) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
+      for (int k = 0; k < (count > 0 ? ord[0] : 0); ++k) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
+    }
     // sum + finalize of projection j on its owner's stream, then hand it to the writer
     auto enqueue_reduce = [&](int j) {
       const int b = j & 1, o = mcgpu_exchange_owner(D[0].x, j);
@@ -391,8 +406,9 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     };
     const double kRad2Deg = 180.0 / 3.14159265358979323846;
     auto print_skipped = [&](int from, int to) {  // offsets [from, to) of the range
-      for (int k = from; k < to && opt->progress; ++k)
-        printf("         << Skipping projection #%d of %d >> Angle %f degrees: outside angular region of interest.\n", first + k + 1, (int)nproj_all,
+      for (int k = from; k < to && opt->progress && phase == 0; ++k)
+        if (outside_roi(first + k))
+          printf("         << Skipping projection #%d of %d >> Angle %f degrees: outside angular region of interest.\n", first + k + 1, (int)nproj_all,
                (angle0 + (first + k) * d_angle) * kRad2Deg);
     };
     for (int i = 0; i < count; ++i) {
@@ -425,7 +441,8 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
       kernel_s += ms * 1e-3;
       t_last_kernel = now_s();
       if (single) publish(i);
-      if (mode == MCGPU_MODE_COMPAT) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
+      if (mode == MCGPU_MODE_COMPAT)
+        for (int k = ord[i]; k < (i + 1 < count ? ord[i + 1] : ord[i] + 1); ++k) cur_seed = mcgpu_advance_seed(1, total, cur_seed);
     }
     print_skipped(count ? sim[count - 1] + 1 : 0, range);
     if (!single && count > 0) { enqueue_reduce(count - 1); publish(count - 1); }
@@ -522,6 +539,122 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     if (d.stream) (void)hipStreamDestroy(d.stream);
   }
   return rc;
+}
+
+// Projection sharding (SURVEY.md 8e's fallback mode; the reference has no counterpart -- its ranks always share a projection,
+// MC-GPU_v1.3.cu:913-1019): context g runs the single-device pipeline over the simulated projections number g, g + n, ... on a
+// thread of its own, with all of their histories.  Nothing crosses between the devices: no exchange, no peer access, no
+// collective.  The MetaImage stacks are shared and filled by slice index; ASCII files are per projection anyway.  Every output
+// byte equals a one-device scan's (per-history streams / per-projection seeds do not depend on who simulates a projection).
+int run_scan_sharing_projections(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
+  mcgpu_stack* stacks[3] = {nullptr, nullptr, nullptr};
+  int rc = 0;
+  std::string error;
+  try {
+    mcgpu_ctx* ctx = ctxs[0];
+    long long nproj_all = 1, nx = 0, nz = 0;
+    ABI_OK(mcgpu_config_i64(ctx, "num_projections", &nproj_all));
+    ABI_OK(mcgpu_config_i64(ctx, "num_pixels_x", &nx));
+    ABI_OK(mcgpu_config_i64(ctx, "num_pixels_z", &nz));
+    double px_x = 0, px_z = 0, d_angle = -1.0, angle0 = 0.0, roi0 = 0.0, roi1 = 0.0;
+    ABI_OK(mcgpu_config_f64(ctx, "pixel_size_x_mm", &px_x));
+    ABI_OK(mcgpu_config_f64(ctx, "pixel_size_z_mm", &px_z));
+    ABI_OK(mcgpu_config_f64(ctx, "D_angle", &d_angle));
+    ABI_OK(mcgpu_config_f64(ctx, "initial_angle", &angle0));
+    ABI_OK(mcgpu_config_f64(ctx, "angularROI_0", &roi0));
+    ABI_OK(mcgpu_config_f64(ctx, "angularROI_1", &roi1));
+    const int first = opt->first_projection > 0 ? opt->first_projection : 0;
+    const int range = (opt->num_projections > 0) ? opt->num_projections : (int)nproj_all - first;
+    if (first + range > nproj_all || range <= 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection range outside the trajectory"};
+    if (opt->projection_stride > 1) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan_multi: MCGPU_SHARD_PROJECTIONS sets the projection stride itself"};
+    // slice of every offset of the range: its ordinal among the simulated projections (the order a one-device scan appends in)
+    std::vector<int> slice_of((size_t)range, -1);
+    int count = 0;
+    for (int k = 0; k < range; ++k) {
+      const double a = angle0 + (first + k) * d_angle;
+      if (!(a < roi0 || a > roi1)) slice_of[(size_t)k] = count++;
+    }
+    const int cx = (opt->crop_nx > 0 && opt->crop_nx < nx) ? opt->crop_nx : (int)nx;
+    const double sx = opt->pixel_spacing_x > 0 ? opt->pixel_spacing_x : px_x, sy = opt->pixel_spacing_y > 0 ? opt->pixel_spacing_y : px_z;
+    std::string folder;
+    if (opt->output_folder) folder = opt->output_folder;
+    else {
+      char name[1024];
+      ABI_OK(mcgpu_projection_file_name(ctx, 0, name, sizeof name));
+      folder = name;
+      const size_t slash = folder.find_last_of('/');
+      folder = slash == std::string::npos ? "." : folder.substr(0, slash);
+    }
+    const bool own_stacks = opt->write_stacks && !opt->shared_stacks && count > 0;
+    if (own_stacks) {
+      static const char* kNames[3] = {"projections_total.mha", "projections_unscattered.mha", "projections_scattered.mha"};
+      for (int k = 0; k < 3; ++k) ABI_OK(mcgpu_stack_create((folder + "/" + kNames[k]).c_str(), cx, (int)nz, count, sx, sy, &stacks[k]));
+    }
+    std::vector<mcgpu_scan_options> o((size_t)n_ctx, *opt);
+    std::vector<mcgpu_scan_report> r((size_t)n_ctx);
+    std::vector<int> rcs((size_t)n_ctx, 0);
+    std::vector<std::string> errs((size_t)n_ctx);
+    std::vector<std::thread> th;
+    const double t0 = now_s();
+    for (int g = 0; g < n_ctx; ++g) {
+      memset(&r[(size_t)g], 0, sizeof(mcgpu_scan_report));
+      o[(size_t)g].shard = MCGPU_SHARD_HISTORIES;  // a single-context scan
+      o[(size_t)g].projection_stride = n_ctx;
+      o[(size_t)g].projection_phase = g;
+      o[(size_t)g].air_stack = nullptr;  // normalisation runs once, below, over the finished stack
+      if (own_stacks) {
+        o[(size_t)g].shared_stacks = stacks;
+        o[(size_t)g].slice_of_projection = slice_of.data();
+      }
+      th.emplace_back([&, g] {
+        rcs[(size_t)g] = run_scan_sharing_histories(&ctxs[g], 1, &o[(size_t)g], &r[(size_t)g]);
+        if (rcs[(size_t)g] != 0) errs[(size_t)g] = mcgpu_last_error();  // the last error is per thread
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n_ctx; ++g)
+      if (rcs[(size_t)g] != 0) throw ScanError{rcs[(size_t)g], errs[(size_t)g]};
+    float repl[3] = {0.f, 0.f, 0.f};
+    if (own_stacks) {
+      for (int k = 0; k < 3; ++k) {
+        mcgpu_stack* st = stacks[k];
+        stacks[k] = nullptr;
+        ABI_OK(mcgpu_stack_finish(st, 1, &repl[k]));
+      }
+      if (opt->air_stack)
+        ABI_OK(mcgpu_normalize_stack((folder + "/projections_total.mha").c_str(), opt->air_stack, opt->air_sigma_y, opt->air_sigma_x,
+                                     (folder + "/projections_total_normalized.mha").c_str(), sx, sy));
+    }
+    if (report) {
+      memset(report, 0, sizeof *report);
+      report->histories_per_projection = r[0].histories_per_projection;
+      report->seconds_total = now_s() - t0;
+      for (int g = 0; g < n_ctx; ++g) {
+        report->projections += r[(size_t)g].projections;
+        report->seconds_kernels = std::max(report->seconds_kernels, r[(size_t)g].seconds_kernels);  // the devices run side by side
+        report->seconds_after_last_kernel = std::max(report->seconds_after_last_kernel, r[(size_t)g].seconds_after_last_kernel);
+        report->seconds_writer += r[(size_t)g].seconds_writer;
+      }
+      for (int k = 0; k < 3; ++k) report->zero_replacement[k] = repl[k];
+    }
+  } catch (const ScanError& e) {
+    error = e.msg;
+    rc = e.code ? e.code : -1;
+  }
+  for (int k = 0; k < 3; ++k)
+    if (stacks[k]) (void)mcgpu_stack_finish(stacks[k], 0, nullptr);  // error path: close the files
+  if (rc != 0) mcgpu_set_last_error_(error.c_str());
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
+  if (!ctxs || n_ctx < 1 || !opt || !ctxs[0]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
+  for (int g = 0; g < n_ctx; ++g)
+    if (!ctxs[g]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null context"); return -1; }
+  if (n_ctx > 1 && opt->shard == MCGPU_SHARD_PROJECTIONS) return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
+  return run_scan_sharing_histories(ctxs, n_ctx, opt, report);
 }
 
 extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {

@@ -21,6 +21,15 @@ def shard_range(units: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi - lo
 
 
+def shard_projections(n_projections: int, rank: int, world: int) -> range:
+    """The projections rank `rank` owns under PROJECTION sharding (SURVEY.md 8e's fallback mode): number rank, rank + world, ...
+    of the simulated ones.  Every rank simulates ALL histories of its projections; nothing is exchanged and no collective runs
+    on the data path.  (The engine's `MCGPU_SHARD_PROJECTIONS` / `MC-GPU_v1.3.x --shard projections` applies the same rule.)"""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return range(rank, n_projections, world)
+
+
 def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "scatter") -> int:
     """Sum the per-rank uint64 tallies (held as an int64 torch tensor, any shape) onto rank `dst`, in place there.
     Returns the payload bytes this rank handed to the collectives.
@@ -88,10 +97,10 @@ def reduce_image(image, dst: int = 0, narrow: bool = True, algorithm: str = "sca
     return send.numel() * send.element_size() + part_w.numel() * part_w.element_size()
 
 
-def connect_exchange(x, dist):
+def connect_exchange(x, dist, group=None):
     """Swap the address cards of a tally exchange (engine.Exchange: IPC memory and event handles of every rank's landing
-    buffer) between the ranks of the initialised process group `dist` (torch.distributed, any backend) and connect this
-    rank's end to every peer.  Collective: every rank calls it once, with `x = None` if it could not even create its end.
+    buffer) between the ranks of the initialised process group `dist` (torch.distributed, any backend; `group`: the group the
+    small control messages travel on, e.g. a gloo group beside an RCCL world) and connect this rank's end to every peer.  Collective: every rank calls it once, with `x = None` if it could not even create its end.
     Returns (ok, error): ok is the SAME on every rank -- False if any rank failed anywhere (no IPC between these devices, an
     interprocess event refused ...), so that all ranks take the same fallback; it never leaves a peer waiting in a collective."""
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -103,7 +112,7 @@ def connect_exchange(x, dist):
         except Exception as e:  # noqa: BLE001 -- reported, and agreed on below
             err = e
     cards = [None] * world
-    dist.all_gather_object(cards, card)
+    dist.all_gather_object(cards, card, group=group)
     if x is None or any(c is None for c in cards):
         err = err or RuntimeError("a rank has no exchange end")
     else:
@@ -114,14 +123,14 @@ def connect_exchange(x, dist):
         except Exception as e:  # noqa: BLE001
             err = e
     flags = [None] * world
-    dist.all_gather_object(flags, err is None)  # also the barrier: nobody starts pushing before everybody has mapped everybody
+    dist.all_gather_object(flags, err is None, group=group)  # also the barrier: nobody starts pushing before everybody has mapped everybody
     if not all(flags):
         return False, err
     try:  # everybody is mapped: can the copy engine of this device reach every peer's landing buffer?
         x.probe()
     except Exception as e:  # noqa: BLE001
         err = e
-    dist.all_gather_object(flags, err is None)
+    dist.all_gather_object(flags, err is None, group=group)
     return all(flags), err
 
 

@@ -170,7 +170,8 @@ def pmc_summary(workload: str):
 
 
 def compat_leg(ctx, torch, H, launches=3):
-    """COMPAT personality (RANECU leap-frog streams, the reference's arithmetic, bit-identical to the oracle) timed like the
+    """COMPAT personality (RANECU leap-frog streams, portable restatement of the reference's arithmetic, bit-identical to the
+    oracle's portable mode) timed like the
     FAST steps: same projection schedule, the reference's launch shape for H histories (MC-GPU_v1.3.cu:824-841)."""
     nz, nx = ctx.detector_shape
     image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
@@ -186,7 +187,7 @@ def compat_leg(ctx, torch, H, launches=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"value": total * launches / dt, "unit": "histories/s", "launches": launches, "histories_per_launch": total, "ms_per_launch": dt / launches * 1e3,
-            "what": "COMPAT kernel: RANECU streams + reference arithmetic, tallies bit-identical to the CPU oracle (tests/test_gpu_fullsize.py)"}
+            "what": "COMPAT kernel: RANECU streams + a portable restatement of the reference arithmetic (own log/pow/sincos, glibc's expf): tallies bit-identical to the CPU oracle's portable mode (tests/test_gpu_fullsize.py), which differs from the reference build on <= 0.2 % of the tally words (last-bit differences of logf; tests/test_gpu_parity.py::test_compat_kernel_against_the_reference_build_itself)"}
 
 
 def fast_vs_compat_check(ctx, runs=12, histories=250_000_000, projection=447):
@@ -383,7 +384,7 @@ def spawn_ranks(n: int) -> int:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--histories", type=float, default=1e8, help="histories per projection per GPU")
@@ -398,6 +399,8 @@ def main():
     ap.add_argument("--ascii-projections", type=int, default=64, help="projections of the end_to_end_ascii leg (63 MB of text each)")
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
+    if args.gpus is None:  # `torchrun ... bench.py` without --gpus: the launcher's rank count is the GPU count
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
 
@@ -438,10 +441,19 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     backend = dist.get_backend() if dist else None
+    # control plane of the fallback decisions: a gloo group beside the RCCL world, so that the ranks can still agree on another
+    # route after an RCCL collective has failed (the verdicts below are a few bytes of host data)
+    ctl = dist.new_group(backend="gloo") if (dist and backend == "nccl") else None
 
     def barrier():
         if dist:
             dist.barrier()
+
+    def agree(ok_here: bool) -> bool:
+        """True iff `ok_here` is true on EVERY rank (all ranks get the same answer)."""
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok_here), group=ctl)
+        return all(flags)
 
     import cases
     eng = cases.pkg.engine
@@ -472,9 +484,15 @@ def main():
     #     its landing buffer with a copy engine while the next projection is tracked, the owner adds them behind its next
     #     kernel (exchange.cpp; the path the drop-in executable runs between its devices)
     #   "rccl": sharding.reduce_image, one collective per G projections between two tracking kernels (exposed by design)
+    #   "none": PROJECTION sharding (SURVEY 8e's fallback): rank r simulates all H histories of its own projections; no exchange,
+    #     no collective on the data path.  Not north_star's split (a projection's histories stay on one GPU): the last line of
+    #     defence on a node where neither the exchange nor RCCL works.  Fallback order: copy -> rccl -> none, agreed by all ranks.
     exchange_kind = os.environ.get("BENCH_EXCHANGE", "copy") if dist else None
+    if exchange_kind not in (None, "copy", "rccl", "none"):
+        raise SystemExit(f"bench.py: BENCH_EXCHANGE={exchange_kind}: expected copy, rccl or none")
     if dist and backend == "gloo" and exchange_kind == "rccl":
         raise SystemExit("bench.py: BENCH_EXCHANGE=rccl needs one GPU per rank")
+    fallbacks = []  # routes tried and given up, with the reason (reported in config.parallelism_fallbacks)
     x = shared_map = None
     policy = eng.EXCHANGE_ROTATE if os.environ.get("MCGPU_EXCHANGE_POLICY", "1") != "0" else eng.EXCHANGE_ROOT0
     if exchange_kind == "copy":
@@ -489,7 +507,7 @@ def main():
             why = None
         except eng.EngineError as e:
             x, why = None, e
-        ok, err = cases.pkg.sharding.connect_exchange(x, dist)  # the same verdict on every rank
+        ok, err = cases.pkg.sharding.connect_exchange(x, dist, group=ctl)  # the same verdict on every rank
         if rank == 0:
             shm.unlink(missing_ok=True)  # every rank holds its mapping
         first_step = 0
@@ -507,20 +525,18 @@ def main():
                 dry = None
             except Exception as e:  # noqa: BLE001 -- reported, and agreed on below
                 dry = e
-            flags = [None] * world
-            dist.all_gather_object(flags, dry is None)
-            ok, err = all(flags), (dry or err)
+            ok, err = agree(dry is None), (dry or err)
             first_step = 2
         if not ok:
             # no IPC between these ranks' devices (or the runtime refused an interprocess event): every rank falls back to the
             # RCCL reduction together -- slower (the collective is exposed between kernels), but a measurement instead of a failure
-            print(f"bench.py: rank {rank}: the tally exchange is not available here ({why or err}); falling back to BENCH_EXCHANGE=rccl", file=sys.stderr)
+            nxt = "none" if backend == "gloo" else "rccl"  # ranks that share a GPU have no RCCL to fall back to
+            print(f"bench.py: rank {rank}: the tally exchange is not available here ({why or err}); falling back to BENCH_EXCHANGE={nxt}", file=sys.stderr)
+            fallbacks.append({"route": "copy", "reason": str(why or err)[:300]})
             if x:
                 x.close()
             x = None
-            if backend == "gloo":
-                raise SystemExit("bench.py: ranks that share a GPU have no RCCL to fall back to")
-            exchange_kind = "rccl"
+            exchange_kind = nxt
     G = max(1, int(os.environ.get("BENCH_REDUCE_GROUP", "8"))) if exchange_kind == "rccl" else 1
     images = None if x else torch.zeros((G, 4, nz, nx), dtype=torch.int64, device="cuda")
     filled = [0]
@@ -547,14 +563,18 @@ def main():
     kernel_events = []     # (start, stop) HIP events around every timed launch, on the stream it is launched on; read after the region
 
     def step(i, timed, hist=H, projection=None):
-        p = (i * 149) % nproj if projection is None else projection  # spread the sampled projections over the arc
+        # spread the sampled projections over the arc; projection sharding: step i of rank r is projection number i * world + r
+        # of that sequence (sharding.shard_projections), simulated whole by this rank
+        k_seq = i * world + rank if exchange_kind == "none" else i
+        p = (k_seq * 149) % nproj if projection is None else projection
+        first_id = 0 if exchange_kind == "none" else rank * hist  # history sharding: disjoint history ids per rank
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
         if x:
             k = n_step[0]
             tally = x.begin(k, stream)
             if ev:
                 ev[0].record()
-            ctx.launch(p, tally, hist, mode="fast", seed=seed, first=rank * hist, stream=stream)  # disjoint history ids per rank
+            ctx.launch(p, tally, hist, mode="fast", seed=seed, first=first_id, stream=stream)
             if ev:
                 ev[1].record()
             x.submit(k, stream)
@@ -565,7 +585,7 @@ def main():
             ctx.clear(image.data_ptr(), stream)
             if ev:
                 ev[0].record()
-            ctx.launch(p, image.data_ptr(), hist, mode="fast", seed=seed, first=rank * hist, stream=stream)
+            ctx.launch(p, image.data_ptr(), hist, mode="fast", seed=seed, first=first_id, stream=stream)
             if ev:
                 ev[1].record()
             filled[0] += 1
@@ -579,14 +599,24 @@ def main():
         collect_up_to(n_step[0])
         reduce_group()
 
+    if exchange_kind == "rccl":
+        # the reductions of the timed region (full groups of G projections and the remainder group) run once untimed: RCCL
+        # sets up its channels and sharding.reduce_image its staging buffers on the first call with a payload shape.  A node
+        # on which that fails makes all ranks take projection sharding together (agreed over the gloo control group).
+        try:
+            for size in sorted({G if args.steps >= G else 0, args.steps % G, G if args.warmup >= G else 0} - {0}):
+                cases.pkg.sharding.reduce_image(images[:size], dst=0, narrow=narrow, algorithm=reduce_algo)
+            torch.cuda.synchronize()
+            trial = None
+        except Exception as e:  # noqa: BLE001 -- reported, and agreed on below
+            trial = e
+        if not agree(trial is None):
+            print(f"bench.py: rank {rank}: the RCCL reduction failed here ({trial}); falling back to projection sharding (BENCH_EXCHANGE=none)", file=sys.stderr)
+            fallbacks.append({"route": "rccl", "reason": str(trial)[:300]})
+            exchange_kind = "none"
     for i in range(args.warmup):
         step(i, False)
-    if exchange_kind == "rccl":
-        drain()
-        # the reductions of the timed region (full groups of G projections and the remainder group) run once untimed: RCCL
-        # sets up its channels and sharding.reduce_image its staging buffers on the first call with a payload shape
-        for size in sorted({G if args.steps >= G else 0, args.steps % G} - {0}):
-            cases.pkg.sharding.reduce_image(images[:size], dst=0, narrow=narrow, algorithm=reduce_algo)
+    drain()
     barrier()
     torch.cuda.synchronize()
     reduce_bytes[0] = 0
@@ -615,6 +645,17 @@ def main():
             owner = x.owner(k_chk)
             if rank == owner:
                 sharded = ctx.download_image(last_reduced[0], stream)
+        elif exchange_kind == "none":
+            # projection sharding: every rank simulates a projection of its own, whole; rank 0 then repeats each of them alone
+            # and compares the words (all ranks run the same code on the same inputs: this checks the plumbing, e.g. that no
+            # rank's tally leaked into another's)
+            owner = 0
+            filled[0] = 0
+            step(0, False, hist=h, projection=(p_chk + rank) % nproj)
+            torch.cuda.synchronize()
+            mine = hashlib.sha256(images[0].cpu().numpy().tobytes()).hexdigest()
+            digests = [None] * world
+            dist.all_gather_object(digests, mine, group=ctl)
         else:
             owner = 0
             step(0, False, hist=h, projection=p_chk)
@@ -624,15 +665,23 @@ def main():
                 sharded = images[0].cpu().numpy().view(np.uint64)
         barrier()
         verdict = None
-        if rank == owner:  # the others idle: one rank simulates ALL the history ids [0, world * h) of that projection alone
+        if exchange_kind == "none":
+            if rank == 0:
+                bad = 0
+                for r_ in range(world):
+                    alone, _, _ = ctx.run_projection((p_chk + r_) % nproj, h, mode="fast", seed=seed, first=0)
+                    bad += int(hashlib.sha256(np.ascontiguousarray(alone).view(np.int64).tobytes()).hexdigest() != digests[r_])
+                verdict = {"passed": bad == 0, "what": "every rank's own projection equals rank 0's run of that projection (SHA-256 of the tally)",
+                           "projections": [(p_chk + r_) % nproj for r_ in range(world)], "histories": h, "ranks": world, "ranks_differing": bad}
+        elif rank == owner:  # the others idle: one rank simulates ALL the history ids [0, world * h) of that projection alone
             alone, _, done = ctx.run_projection(p_chk, world * h, mode="fast", seed=seed, first=0)
             verdict = {"passed": bool(np.array_equal(alone, sharded)), "projection": p_chk, "histories_per_rank": h, "ranks": world,
                        "checked_on_rank": rank, "words_differing": int(np.count_nonzero(alone != sharded)),
                        "detected_energy_units": int(alone.sum())}
         verdicts = [None] * world
-        dist.all_gather_object(verdicts, verdict)
+        dist.all_gather_object(verdicts, verdict, group=ctl)
         stats = [None] * world
-        dist.all_gather_object(stats, (x.stats() if x else None, float(np.mean(kernel_ms))))
+        dist.all_gather_object(stats, (x.stats() if x else None, float(np.mean(kernel_ms))), group=ctl)
         multi = {"sharded_equals_single": verdicts[owner], "stats": stats}
 
     detected = 0
@@ -651,9 +700,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
                        "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
-                       "parallelism": f"history-sharded x{world}" + ("" if not dist else
+                       "parallelism": (f"PROJECTION-sharded x{world}: every rank simulates whole projections, no exchange and no collective (SURVEY 8e fallback mode; NOT north_star's history split)"
+                                       if exchange_kind == "none" else
+                                       f"history-sharded x{world}" + ("" if not dist else
                                       (", tally exchange: copy-engine pushes to the projection's owner (" + ("owner = projection mod ranks" if policy == eng.EXCHANGE_ROTATE else "owner = rank 0") + "), one fused add per projection"
-                                       if x else f", one RCCL sum-reduction ({reduce_algo}) of the detector tallies per {G} projections")),
+                                       if x else f", one RCCL sum-reduction ({reduce_algo}) of the detector tallies per {G} projections"))),
+                       "parallelism_route": exchange_kind, "parallelism_fallbacks": fallbacks if dist else None,
                        "ranks_started_by": "bench.py itself" if os.environ.get("BENCH_SPAWNED") else ("an external launcher" if dist else "single process"),
                        "process_group_backend": backend, "ranks_share_gpus": bool(share and world > n_dev),
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
@@ -670,7 +722,7 @@ def main():
         }
         if multi:
             v = multi["sharded_equals_single"]
-            out["check"]["sharded_equals_single"] = v
+            out["check"]["projection_sharded_equals_single" if exchange_kind == "none" else "sharded_equals_single"] = v
             out["check"]["passed"] = bool(v and v["passed"])
             failed = failed or not out["check"]["passed"]
             k_all = [s_[1] for s_ in multi["stats"]]
@@ -694,7 +746,7 @@ def main():
                             "exposed_ms_per_step_on_the_critical_rank": (float(np.max(add)) if add else 0.0) * (1.0 / world if policy == eng.EXCHANGE_ROTATE else 1.0),
                             "host_wait_s_per_rank": [a["host_wait_s"] for a in st],
                             "owner_policy": "rotate" if policy == eng.EXCHANGE_ROTATE else "rank0"})
-            else:
+            elif exchange_kind == "rccl":
                 red.update({"bytes_per_rank_in_timed_region": reduce_bytes[0], "narrowed_to_u32_when_it_fits": bool(narrow), "algorithm": reduce_algo,
                             "projections_per_reduction": G})
             out["reduce"] = red

@@ -198,7 +198,17 @@ typedef struct mcgpu_scan_options {
   mcgpu_stack **shared_stacks;
   const int *slice_of_projection;
   int progress;                                 /* print the reference's "<< Simulating Projection i of n >>" lines to stdout */
+  /* mcgpu_run_scan_multi: how the work is split over the contexts.  MCGPU_SHARD_HISTORIES (0, default): the reference's split
+   * (every projection's histories over the devices, tallies summed; MC-GPU_v1.3.cu:728-731, :1019).  MCGPU_SHARD_PROJECTIONS:
+   * context g simulates ALL histories of the simulated projections number g, g + n, g + 2n, ... and nothing crosses between the
+   * devices (SURVEY.md 8e's fallback: no exchange, no collective); outputs are identical to a one-device scan. */
+  int shard;
+  /* simulate only the simulated projections number phase, phase + stride, ... of the range (0, 0 = all): what
+   * MCGPU_SHARD_PROJECTIONS hands to each context; usable directly by a host that runs one mcgpu_run_scan per device */
+  int projection_stride, projection_phase;
 } mcgpu_scan_options;
+#define MCGPU_SHARD_HISTORIES 0
+#define MCGPU_SHARD_PROJECTIONS 1
 typedef struct mcgpu_scan_report {
   int projections;
   unsigned long long histories_per_projection;

@@ -76,6 +76,21 @@ def test_shard_range_partitions_exactly():
         sr(10, 2, 2)
 
 
+def test_shard_projections_partitions_exactly():
+    """Projection sharding (SURVEY 8e's fallback, `BENCH_EXCHANGE=none` / `--shard projections`): the union of the ranks'
+    projection sets is the trajectory, exactly once each, balanced to within one projection."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import cases
+    sp = cases.pkg.sharding.shard_projections
+    for n in (0, 1, 7, 894, 8940):
+        for world in (1, 2, 3, 4, 8):
+            parts = [list(sp(n, r, world)) for r in range(world)]
+            assert sorted(p for part in parts for p in part) == list(range(n))
+            assert max(len(part) for part in parts) - min(len(part) for part in parts) <= 1
+    with pytest.raises(ValueError):
+        sp(10, 2, 2)
+
+
 def test_two_rank_history_sharding_reduces_to_single_process_image(case_dir, tmp_path):
     import cases
     import oracle_lib as ol

@@ -166,11 +166,15 @@ def _stream_statistics(ctx, generator, n_ids_log2=24, n_draws=32, seed=20240607,
 
 @pytest.mark.gpu
 def test_stream_statistics_against_philox_per_draw_yardstick(ctx):
-    """2^24 consecutive history ids x 32 deviates (a history of the bench workloads consumes ~16-40).  Every statistic is a
-    z-score; the production generator must stay below 4.5 (the worst of ~32 looks: 4 sigma on one of them happens by chance once
-    in 500 runs) wherever the yardstick does, and a yardstick failure would mean the test itself is broken."""
-    prod = _stream_statistics(ctx, generator=0)
-    yard = _stream_statistics(ctx, generator=1)
+    """2^22 consecutive history ids (MCGPU_RNG_TEST_LOG2=24: 2^24, the run recorded under profiles/) x 32 deviates (a history of
+    the bench workloads consumes ~16-40).  Every statistic is a z-score; the production generator must stay below 4.5 (the worst
+    of ~32 looks: 4 sigma on one of them happens by chance once in 500 runs) wherever the yardstick does, and a yardstick failure
+    would mean the test itself is broken."""
+    import os
+    log2 = int(os.environ.get("MCGPU_RNG_TEST_LOG2", "22"))
+    prod = _stream_statistics(ctx, generator=0, n_ids_log2=log2)
+    yard = _stream_statistics(ctx, generator=1, n_ids_log2=log2)
+    print("history ids: 2^%d x 32 deviates" % log2)
     print("production (Philox4x32-7 -> MWC):", {k: round(v, 2) for k, v in prod.items()})
     print("yardstick  (Philox4x32-10 per draw):", {k: round(v, 2) for k, v in yard.items()})
     for k, v in yard.items():

@@ -146,6 +146,36 @@ def test_executable_sharded_over_devices_equals_single_device(engine, tmp_path):
         assert s1.shape == (4, 96, 128) and np.array_equal(s1, s2), m
 
 
+@pytest.mark.parametrize("mode", ["fast", "compat"])
+def test_executable_sharded_by_projection_equals_single_device(engine, tmp_path, mode):
+    """`--shard projections` (SURVEY 8e's fallback: every device simulates whole projections, nothing crosses between devices):
+    three "devices" over eight projections, the first of them outside the angular region of interest -- seven simulated, so the
+    shares are uneven and the skipped projection shifts the ownership, and in COMPAT mode the seed must still move on once per simulated projection
+    whoever simulates it (MC-GPU_v1.3.cu:869).  Files and stacks must equal the single-device run's byte for byte."""
+    kw = dict(n_histories=120_000, n_projections=8, angle_between_projections=50.0)
+    a = cases.build_case("catphan64_ct", tmp_path / "one", **kw)
+    b = cases.build_case("catphan64_ct", tmp_path / "three", **kw)
+    for inp in (a, b):  # the trajectory starts at 270 degrees: an angular ROI from 300 degrees drops projection #1
+        text = inp.read_text()
+        assert "0.0 5000.0  # ANGLES OF INTEREST" in text
+        inp.write_text(text.replace("0.0 5000.0  # ANGLES OF INTEREST", "300.0 5000.0  # ANGLES OF INTEREST"))
+    common = ["--stacks", "--crop", "128", "--mode", mode]
+    r1 = subprocess.run([str(engine.EXE_PATH), str(a)] + common, capture_output=True, text=True, timeout=600)
+    r3 = subprocess.run([str(engine.EXE_PATH), str(b), "--devices", "0,0,0", "--shard", "projections"] + common, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and r3.returncode == 0, r1.stdout[-2000:] + r3.stdout[-2000:]
+    assert not re.search("(?i)error", r1.stdout + r3.stdout)
+    assert sorted(int(v) for v in re.findall(r"<< Simulating Projection (\d+) of 8 >>", r3.stdout)) == [2, 3, 4, 5, 6, 7, 8]
+    assert [int(v) for v in re.findall(r"Skipping projection #(\d+) of 8", r3.stdout)] == [1]
+    names = sorted(f.name for f in (tmp_path / "one").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
+    assert len(names) == 7
+    data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]
+    for n in names:
+        assert data(tmp_path / "one" / n) == data(tmp_path / "three" / n), n
+    for m in ("total", "unscattered", "scattered"):
+        s1, s3 = engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / "three" / f"projections_{m}.mha")
+        assert s1.shape == (7, 96, 128) and np.array_equal(s1, s3), m
+
+
 def test_reference_command_line_through_the_mpirun_shim(engine, tmp_path):
     """What `MCSimulation.run_simulation` executes inside the container (cbctmc/mc/simulation.py:187-198): `mpirun --tag-output
     -v -n <gpus> MC-GPU_v1.3.x <input>`, its stdout scanned for progress lines and for the word "error", its projection files

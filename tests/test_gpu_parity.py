@@ -103,6 +103,30 @@ def test_compat_kernel_bit_exact_vs_oracle(gpu_engine, case_dir, name, nbatch):
             assert diff == 0, f"{name} projection {p}: {diff} tally words differ"
 
 
+@pytest.mark.parametrize("name", [c for c, _ in CASE_BATCHES] + ["catphan64_dose"])
+def test_compat_kernel_against_the_reference_build_itself(gpu_engine, case_dir, name):
+    """Closes the chain GPU -> portable oracle -> libm oracle -> reference ON THE GPU BOX: tests/golden/case_*.npz holds the tallies
+    of the reference's own C code compiled where it lies (`ref_*`, oracle/gen_golden.py from oracle/_ref) and of the portable
+    restatement (`portable_*`) for the same batches.  The COMPAT kernel must equal the portable fixture word for word and may
+    differ from the REFERENCE BUILD only where the portable logarithm / power / sine differ from glibc's in the last bit
+    (pm_log vs logf: 4.2e5 of 2.1e9 floats) -- the budget tests/test_oracle_golden.py states for the two CPU modes."""
+    import golden_util as gu
+    g = gu.load(f"case_{name}.npz")
+    nb, hpt = [int(v) for v in g["nbatch_hpt"]]
+    with gpu_engine.create(case_dir(name), device=0) as ctx:
+        size = int(np.prod(ctx.detector_shape)) * 4
+        for p in range(ctx.num_projections):
+            img, _, done = ctx.run_projection(p, nb, mode="compat", seed=42 + 1000 * p, hpt=hpt)
+            assert done == nb * hpt
+            got = img.reshape(-1)
+            assert np.array_equal(got, gu.dense(g, "portable", p, size)), f"{name} p{p}: differs from the portable-math fixture"
+            ref = gu.dense(g, "ref", p, size)
+            ndiff = np.count_nonzero(got != ref)
+            assert ndiff <= max(8, np.count_nonzero(ref) // 500), f"{name} p{p}: {ndiff} tally words differ from the reference build"
+            # the words that differ come in pairs (a history scored one pixel over, or with one unit less): energy is conserved
+            assert abs(int(got.sum()) - int(ref.sum())) <= 1e-6 * int(ref.sum())
+
+
 def test_compat_history_sharding_is_exact(gpu_engine, case_dir):
     """Two ranks given disjoint batch ranges sum to the single-GPU image (what the multi-GPU reduce relies on)."""
     with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
