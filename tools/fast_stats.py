@@ -42,8 +42,8 @@ for wl in args.workloads:
                 "rayleigh": round(s["cycles_rayleigh"] / tot, 3), "tally_source": round(s["cycles_new"] / tot, 3),
                 "ballots_trades_exchanges": round((sc - s["cycles_settle"] - services) / tot, 3)},
             "wave_cycles_per_history": round(tot / done, 1),
-            "flight": {"iterations_per_history": per("iterations"), "steps_per_history": per("flying_lanes"),
-                       "lanes_per_iteration": round(s["flying_lanes"] / it, 2), "iterations_per_sched_point": round(it / sp, 2),
+            "flight": {"iterations_per_history": per("iterations"), "steps_per_history": per("lanes_both_flyable"),
+                       "lanes_still_flying_after_an_iteration": round(s["flying_lanes"] / it, 2), "lanes_taking_a_step_per_iteration": round(s["lanes_both_flyable"] / it, 2), "iterations_per_sched_point": round(it / sp, 2),
                        "voxel_loads_per_history": per("voxel_load_lanes"), "iterations_with_voxel_load": round(s["iter_with_voxel_load"] / it, 3),
                        "exact_sigma_loads_per_history": per("sigma_load_lanes"), "iterations_with_sigma_load": round(s["iter_with_sigma_load"] / it, 3)},
             "compton": {"batches_per_history": per("compton_rounds"), "lanes_per_batch": round(s["compton_lanes"] / max(s["compton_rounds"], 1), 1),
@@ -55,5 +55,5 @@ for wl in args.workloads:
             "rayleigh": {"batches_per_history": per("rayleigh_rounds"), "lanes_per_batch": round(s["rayleigh_lanes"] / max(s["rayleigh_rounds"], 1), 1)},
             "tally_source": {"batches_per_history": per("new_rounds"), "lanes_per_batch": round(s["new_lanes"] / max(s["new_rounds"], 1), 1)},
             "sched_points_per_history": per("scheduling_points"), "drain_fraction": round(s["drain_points"] / sp, 3),
-            "pool_after_sched_point": {k: round(s[k] / sp, 1) for k in ("pool_flyable", "pool_wants_new", "pool_compton", "lanes_both_flyable")},
+            "pool_after_sched_point": {k: round(s[k] / sp, 1) for k in ("pool_flyable", "pool_wants_new", "pool_compton")},
             "slots_traded_per_sched_point": round(s["slots_traded"] / sp, 2)}), flush=True)
