@@ -44,10 +44,6 @@ inline unsigned int tiled_voxel(unsigned int ix, unsigned int iy, unsigned int i
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kPoolParked = 1;            // FAST kernel: histories a lane parks in LDS slots beside the one in its registers
-// FAST kernel: real interactions / exterior hops are settled INSIDE the flight loop (their records requested at the end of the
-// iteration that produced them, used one iteration later behind that iteration's voxel wait) and the lane is refilled from its
-// parked flyable histories at once, instead of idling until the next scheduling point (track_pool.inc)
-constexpr bool kPoolPipelined = false;
 constexpr int kPoolWavesPerSimd = 2 * kPoolBlockThreads / 64 / 4;  // two workgroups per CU (each gets half of the 160 KB of LDS)
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)

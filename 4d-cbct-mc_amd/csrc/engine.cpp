@@ -115,7 +115,6 @@ struct DeviceModel {
     int grid_spare_percent = 0;                      // MCGPU_GRID_SPARE_PERCENT
     int sched_override[5] = {-1, -1, -1, -1, -1};    // MCGPU_THRESH_{COMPTON,RAYLEIGH,NEW}, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH (-1: sched[])
     int slot_trade = 3, hold_q = 6;                  // MCGPU_SLOT_TRADE, MCGPU_HOLD_Q
-    int refill_min = 6;                              // MCGPU_REFILL_MIN (pipelined FAST kernel: lanes that make an in-loop refill worth its exchange)
     bool no_exterior = false;                        // MCGPU_NO_EXTERIOR (also read by the geometry builders)
   } knobs;
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
@@ -190,7 +189,6 @@ void read_env_knobs(DeviceModel& D) {
   for (int i = 0; i < 5; ++i) k.sched_override[i] = env_int(kSched[i], -1);
   k.slot_trade = env_int("MCGPU_SLOT_TRADE", 3);
   k.hold_q = env_int("MCGPU_HOLD_Q", 6) & 15;
-  k.refill_min = std::min(std::max(env_int("MCGPU_REFILL_MIN", 6), 1), 64);
   k.no_exterior = getenv("MCGPU_NO_EXTERIOR") != nullptr;
   D.knobs = k;
 }
@@ -207,8 +205,7 @@ void apply_schedule(DeviceModel& D) {
   want[4] = std::max(1, want[4]);
   // bit 0: slots traded before flight, bit 1: before the Compton and tally/source services; bits 8-11: hold_q (sixteenths
   // of the flying lanes that end a flight segment at the latest)
-  // bits 12-18: refill_min of the pipelined kernel
-  const int trade = (D.knobs.slot_trade & 3) | (D.knobs.hold_q << 8) | (D.knobs.refill_min << 12);
+  const int trade = D.knobs.slot_trade | (D.knobs.hold_q << 8);
   if (ch.trade_slots == trade && ch.thresh_compton == want[0] && ch.thresh_rayleigh == want[1] && ch.thresh_new == want[2] && ch.flyable_low == want[3] &&
       ch.swap_batch == want[4])
     return;

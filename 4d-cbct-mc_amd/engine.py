@@ -420,7 +420,7 @@ class Context:
         _check(self.lib.mcgpu_scheduler_stats_ex(self.h, out, 32, int(reset)))
         names = ("iterations", "flying_lanes", "compton_rounds", "compton_lanes", "rayleigh_rounds", "rayleigh_lanes", "new_rounds", "new_lanes",
                  "scheduling_points", "take_rounds", "take_lanes", "drain_points", "cycles_compton", "cycles_rayleigh", "cycles_new", "cycles_flight",
-                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "slots_traded", "lanes_both_flyable",
+                 "compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes", "pool_flyable", "pool_wants_new", "pool_compton", "slots_traded", "lanes_taking_a_step",
                  "iter_with_voxel_load", "voxel_load_lanes", "iter_with_sigma_load", "sigma_load_lanes",
                  "cycles_flight_to_voxel", "cycles_flight_resolve", "cycles_settle", "cycles_sched_point")
         return dict(zip(names, [int(v) for v in out]))

@@ -33,7 +33,7 @@ with eng.create(inp, device=0) as ctx:
                                              "shell_lanes_per_round": round(s["compton_shell_lanes"] / max(s["compton_rounds"], 1), 1),
                                              "done_per_round": round(s["compton_done_lanes"] / max(s["compton_rounds"], 1), 1)},
                           "pool_after_sched_point": {k: round(s[k] / max(s["scheduling_points"], 1), 1) for k in
-                                                     ("pool_flyable", "pool_wants_new", "pool_compton", "lanes_both_flyable")},
+                                                     ("pool_flyable", "pool_wants_new", "pool_compton")},
                           "per_history": {"flight_steps": round(s["flying_lanes"] / done, 3), "voxel_loads": round(s["voxel_load_lanes"] / done, 3),
                                           "exact_sigma_loads": round(s["sigma_load_lanes"] / done, 3),
                                           "real_records": round((s["compton_done_lanes"]) / done, 3)},

@@ -42,8 +42,8 @@ for wl in args.workloads:
                 "rayleigh": round(s["cycles_rayleigh"] / tot, 3), "tally_source": round(s["cycles_new"] / tot, 3),
                 "ballots_trades_exchanges": round((sc - s["cycles_settle"] - services) / tot, 3)},
             "wave_cycles_per_history": round(tot / done, 1),
-            "flight": {"iterations_per_history": per("iterations"), "steps_per_history": per("lanes_both_flyable"),
-                       "lanes_still_flying_after_an_iteration": round(s["flying_lanes"] / it, 2), "lanes_taking_a_step_per_iteration": round(s["lanes_both_flyable"] / it, 2), "iterations_per_sched_point": round(it / sp, 2),
+            "flight": {"iterations_per_history": per("iterations"), "steps_per_history": per("lanes_taking_a_step"),
+                       "lanes_still_flying_after_an_iteration": round(s["flying_lanes"] / it, 2), "lanes_taking_a_step_per_iteration": round(s["lanes_taking_a_step"] / it, 2), "iterations_per_sched_point": round(it / sp, 2),
                        "voxel_loads_per_history": per("voxel_load_lanes"), "iterations_with_voxel_load": round(s["iter_with_voxel_load"] / it, 3),
                        "exact_sigma_loads_per_history": per("sigma_load_lanes"), "iterations_with_sigma_load": round(s["iter_with_sigma_load"] / it, 3)},
             "compton": {"batches_per_history": per("compton_rounds"), "lanes_per_batch": round(s["compton_lanes"] / max(s["compton_rounds"], 1), 1),

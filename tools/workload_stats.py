@@ -38,7 +38,7 @@ for wl in (sys.argv[1:] or ["catphan", "cirs", "thorax"]):
         out["compton_angle_shell_done_lanes"] = [round(s[k] / max(s["compton_rounds"], 1), 1) for k in ("compton_angle_lanes", "compton_shell_lanes", "compton_done_lanes")]
         out["cycles_per_hist"] = {k[7:]: round(s[k] / done) for k in s if k.startswith("cycles_")}
         sp = max(s["scheduling_points"], 1)
-        out["after_sched_point"] = {k: round(s[k] / sp, 1) for k in ("pool_flyable", "pool_wants_new", "pool_compton", "slots_traded", "lanes_both_flyable", "take_lanes")}
+        out["after_sched_point"] = {k: round(s[k] / sp, 1) for k in ("pool_flyable", "pool_wants_new", "pool_compton", "slots_traded", "take_lanes")}
         out["voxel_load_iter_frac"] = round(s["iter_with_voxel_load"] / max(s["iterations"], 1), 3)
         out["sigma_load_iter_frac"] = round(s["iter_with_sigma_load"] / max(s["iterations"], 1), 3)
     print(json.dumps(out))
