@@ -25,7 +25,11 @@ namespace mcgpu {
 hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
 int occupancy_track_fast(const TrackArgs& args);
-hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);
+#if defined(MC_WITH_STATS) && MC_WITH_STATS
+hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);  // diagnostic library only (track_stats.o)
+#endif
+hipError_t microbench_valu_issue(int num_cus, double out3[3], hipStream_t stream);
+hipError_t microbench_atomic_rate(double* out, hipStream_t stream);
 hipError_t launch_kat_rng(int mode, int seed, int batch, int hpt, int n, float* out_dev, hipStream_t stream);
 hipError_t launch_kat_streams_fast(int generator, unsigned int seed, unsigned int stream_key, unsigned long long first_id,
                                    const unsigned long long* ids_dev, int n_ids, int n_draws, unsigned int* out_dev, hipStream_t stream);
@@ -1068,9 +1072,13 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       HIP_TRY(hipMemsetAsync(D.work_counter, 0, (size_t)kNumCounters * kCounterStride * 8, stream));
       A.work_counter = D.work_counter;
       if (mode == MCGPU_MODE_FAST_STATS) {
+#if defined(MC_WITH_STATS) && MC_WITH_STATS
         if (!D.stats) D.stats = D.put(std::vector<unsigned long long>(kNumStats + 3 * kWaveTrace, 0ULL));
         A.stats = D.stats;
         HIP_TRY(launch_track_stats(A, (int)std::min(want, resident), stream));
+#else
+        throw Error(-2, "!!ERROR!! mcgpu_launch_projection: MCGPU_MODE_FAST_STATS needs the diagnostic library (libmcgpu_amd_stats.so, MCGPU_AMD_LIB)");
+#endif
       } else {
         HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
       }
@@ -1628,6 +1636,18 @@ int mcgpu_write_voxel_binary(const char* path, const int n[3], const float spaci
   ABI_BEGIN
   require(path && n && spacing_cm && material && density, -1, "!!ERROR!! mcgpu_write_voxel_binary: null argument");
   write_voxel_binary(path, n, spacing_cm, material, density);
+  return 0;
+  ABI_END
+}
+
+int mcgpu_microbench(mcgpu_ctx* ctx, int kind, double* out, int n_out) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && out && ((kind == MCGPU_MICROBENCH_VALU_ISSUE && n_out >= 3) || (kind == MCGPU_MICROBENCH_ATOMIC_RATE && n_out >= 1)), -1,
+          "!!ERROR!! mcgpu_microbench: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  if (kind == MCGPU_MICROBENCH_VALU_ISSUE) HIP_TRY(microbench_valu_issue(ctx->dev.num_cus, out, nullptr));
+  else HIP_TRY(microbench_atomic_rate(out, nullptr));
   return 0;
   ABI_END
 }

@@ -316,6 +316,11 @@ int mcgpu_exchange_owner(const mcgpu_exchange* x, long long step) { return x ? x
 int mcgpu_exchange_begin(mcgpu_exchange* x, long long step, void* hip_stream, void** tally) {
   X_BEGIN
   X_REQUIRE(x && tally && step >= 0, "!!ERROR!! mcgpu_exchange_begin: bad argument");
+  // the buffer is zeroed here: its previous user, step - 2, must be done with it on this stream -- submitted, and collected if
+  // this rank owned it (a caller that lags its collects by more than one step would otherwise lose an unreduced tally silently)
+  X_REQUIRE(step == x->last_submitted + 1, "!!ERROR!! mcgpu_exchange_begin: steps are consecutive (begin, launch, submit)");
+  X_REQUIRE(step < 2 || x->owner(step - 2) != x->rank || x->last_collected >= step - 2,
+            "!!ERROR!! mcgpu_exchange_begin: the tally of step - 2 has not been collected yet (its buffer would be zeroed)");
   X_HIP(hipSetDevice(x->device));
   const int b = (int)(step & 1);
   hipStream_t s = (hipStream_t)hip_stream;

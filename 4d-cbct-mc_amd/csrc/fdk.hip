@@ -292,8 +292,17 @@ struct FdkError { std::string msg; };
 
 }  // namespace
 
-extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* o, const float* projections, float* volume, mcgpu_fdk_report* report) {
-  if (!o || !projections || !volume || o->n_proj < 1 || o->nu < 2 || o->nv < 2 || o->nx < 1 || o->ny < 1 || o->nz < 1 || !o->gantry_deg ||
+extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* caller_o, const float* projections, float* volume, mcgpu_fdk_report* report) {
+  if (!caller_o || caller_o->struct_size < 2 * sizeof(int)) {
+    mcgpu_set_last_error_("!!ERROR!! mcgpu_fdk_reconstruct: set mcgpu_fdk_options.struct_size = sizeof(mcgpu_fdk_options)");
+    return -1;
+  }
+  // a caller built against an older header passes a shorter struct: what it does not have (e.g. `pad`) reads as zero
+  mcgpu_fdk_options local;
+  memset(&local, 0, sizeof local);
+  memcpy(&local, caller_o, std::min<size_t>(caller_o->struct_size, sizeof local));
+  const mcgpu_fdk_options* o = &local;
+  if (!projections || !volume || o->n_proj < 1 || o->nu < 2 || o->nv < 2 || o->nx < 1 || o->ny < 1 || o->nz < 1 || !o->gantry_deg ||
       !(o->du > 0) || !(o->dv > 0) || !(o->sid > 0) || !(o->sdd > 0)) {
     mcgpu_set_last_error_("!!ERROR!! mcgpu_fdk_reconstruct: bad argument");
     return -1;

@@ -92,6 +92,7 @@ int main(int argc, char** argv) {
 
   mcgpu_scan_options so;
   memset(&so, 0, sizeof so);
+  so.struct_size = (unsigned int)sizeof so;
   so.mode = mode;
   so.progress = 1;
   so.shard = shard;

@@ -649,8 +649,18 @@ int run_scan_sharing_projections(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_
 
 }  // namespace
 
-extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
-  if (!ctxs || n_ctx < 1 || !opt || !ctxs[0]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
+extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* caller_opt, mcgpu_scan_report* report) {
+  if (!ctxs || n_ctx < 1 || !caller_opt || !ctxs[0]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null argument"); return -1; }
+  // a caller built against an older header passes a shorter struct: what it does not have reads as zero
+  if (caller_opt->struct_size < sizeof(unsigned int) + sizeof(int)) {
+    mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: set mcgpu_scan_options.struct_size = sizeof(mcgpu_scan_options)");
+    return -1;
+  }
+  mcgpu_scan_options local;
+  memset(&local, 0, sizeof local);
+  memcpy(&local, caller_opt, std::min<size_t>(caller_opt->struct_size, sizeof local));
+  local.struct_size = (unsigned int)sizeof local;
+  const mcgpu_scan_options* opt = &local;
   for (int g = 0; g < n_ctx; ++g)
     if (!ctxs[g]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null context"); return -1; }
   if (n_ctx > 1 && opt->shard == MCGPU_SHARD_PROJECTIONS) return run_scan_sharing_projections(ctxs, n_ctx, opt, report);

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
-    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_microbench", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
     "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
     "mcgpu_exchange_connect_local", "mcgpu_exchange_probe", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
     "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
 
 class ScanOptions(C.Structure):
     """mcgpu_scan_options (include/mcgpu_amd.h)."""
-    _fields_ = [("mode", C.c_int), ("first_projection", C.c_int), ("num_projections", C.c_int),
+    _fields_ = [("struct_size", C.c_uint), ("mode", C.c_int), ("first_projection", C.c_int), ("num_projections", C.c_int),
                 ("histories_per_projection", C.c_ulonglong), ("crop_nx", C.c_int), ("write_ascii", C.c_int), ("write_stacks", C.c_int),
                 ("output_folder", C.c_char_p), ("air_stack", C.c_char_p), ("air_sigma_y", C.c_double), ("air_sigma_x", C.c_double),
                 ("pixel_spacing_x", C.c_double), ("pixel_spacing_y", C.c_double),
@@ -118,6 +118,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_write_voxel_file.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp, ci]
     lib.mcgpu_write_voxel_binary.argtypes = [cp, C.POINTER(ci), C.POINTER(C.c_float), vp, vp]
     lib.mcgpu_kat_rng.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+    lib.mcgpu_microbench.argtypes = [vp, ci, vp, ci]
     lib.mcgpu_kat_rng_streams.argtypes = [vp, ci, C.c_uint, C.c_uint, C.c_ulonglong, vp, ci, ci, vp]
     lib.mcgpu_reload_env_knobs.argtypes = [vp]
     lib.mcgpu_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
@@ -256,17 +257,25 @@ class Exchange:
 
     @staticmethod
     def open_shared(path, world: int, create: bool):
-        """Map the host region of an exchange between processes: rank 0 creates (and zeroes) the file BEFORE the others open it."""
+        """Map the host region of an exchange between processes: rank 0 creates (and zeroes) the file BEFORE the others open it.
+        The creator replaces whatever sits at `path` with a NEW inode of mode 0600 (O_EXCL | O_NOFOLLOW: a symlink planted in the
+        world-writable directory is not followed, and a rank left over from a crashed run on the same port keeps its old inode
+        instead of sharing counters with this run)."""
         import mmap
         n = Exchange.shared_bytes(world)
         if create:
-            with open(path, "wb") as f:
-                f.write(b"\0" * n)
-        f = open(path, "r+b")
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
+            fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+            os.ftruncate(fd, n)  # zero-filled
+        else:
+            fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
         try:
-            return mmap.mmap(f.fileno(), n)
+            return mmap.mmap(fd, n)
         finally:
-            f.close()
+            os.close(fd)
 
     def card(self) -> bytes:
         n = int(self.lib.mcgpu_exchange_card_bytes(self.world))
@@ -532,6 +541,7 @@ class Context:
         `peers` + shard="histories": the reference's split (tallies summed through the exchange); shard="projections": every
         context simulates whole projections, nothing crosses between devices (SURVEY 8e fallback)."""
         o = ScanOptions()
+        o.struct_size = C.sizeof(ScanOptions)
         o.shard = {"histories": 0, "projections": 1}[shard]
         o.projection_stride, o.projection_phase = int(projection_stride), int(projection_phase)
         if shared_stacks is not None:
@@ -598,6 +608,13 @@ class Context:
             name = self.write_projection(p, img, done, secs) if write_projections else None
             out.append((name, img, secs, done))
         return out
+
+    def microbench(self, kind: str):
+        """Hardware ceilings measured on this context's device (include/mcgpu_amd.h: mcgpu_microbench): kind "valu_issue" ->
+        wave-instructions per ns and SIMD {64 lanes, lanes 0-31, 32 lanes spread}; "atomic_rate" -> scattered 64-bit adds per second."""
+        out = (C.c_double * 3)()
+        _check(self.lib.mcgpu_microbench(self.h, {"valu_issue": 0, "atomic_rate": 1}[kind], out, 3))
+        return [float(v) for v in out] if kind == "valu_issue" else float(out[0])
 
     # -- known-answer hooks
     def kat_rng(self, mode, seed: int, batch: int, hpt: int, n: int) -> np.ndarray:

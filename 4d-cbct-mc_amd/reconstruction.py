@@ -103,7 +103,7 @@ def save_geometry(geometry: CircularGeometry, output_filepath) -> Path:
 
 
 class _FdkOptions(C.Structure):
-    _fields_ = [("n_proj", C.c_int), ("nu", C.c_int), ("nv", C.c_int), ("du", C.c_double), ("dv", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
+    _fields_ = [("struct_size", C.c_uint), ("n_proj", C.c_int), ("nu", C.c_int), ("nv", C.c_int), ("du", C.c_double), ("dv", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("sid", C.c_double), ("sdd", C.c_double), ("gantry_deg", C.POINTER(C.c_double)), ("proj_offset_x", C.POINTER(C.c_double)),
                 ("proj_offset_y", C.POINTER(C.c_double)), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("sx", C.c_double), ("sy", C.c_double),
                 ("sz", C.c_double), ("ox", C.c_double), ("oy", C.c_double), ("oz", C.c_double), ("hann", C.c_double), ("hann_y", C.c_double),
@@ -119,7 +119,10 @@ def fdk(projections: np.ndarray, geometry: CircularGeometry, pixel_spacing: Tupl
         origin: Optional[Tuple[float, float, float]] = None, hann: float = 0.0, hann_y: float = 0.0,
         water_pre_correction: Optional[Sequence[float]] = None, gpu_id: int = 0, pad: float = 0.0):
     """projections [n, nv, nu] (line integrals) -> (volume [nz, ny, nx] float32 in RTK's IEC frame, report dict).
-    pad: rtkfdk --pad, the truncation correction of RTK's ramp filter (0 = rows are zero-padded only)."""
+    pad: rtkfdk --pad, the truncation correction of RTK's ramp filter (0 = rows are zero-padded only).  It follows the published
+    heuristic only: the exact extent / weight table of RTK's FFTProjectionsConvolutionImageFilter (floor vs ceil of pad x width, the
+    mirror limited by the zero extension) could not be checked against RTK here -- on a truncated half-fan scan the feathered edge
+    may differ from rtkfdk's (parity unpinned)."""
     from . import engine
     lib = engine.load_library()
     lib.mcgpu_fdk_reconstruct.argtypes = [C.POINTER(_FdkOptions), C.c_void_p, C.c_void_p, C.POINTER(_FdkReport)]
@@ -135,7 +138,7 @@ def fdk(projections: np.ndarray, geometry: CircularGeometry, pixel_spacing: Tupl
     oy = np.ascontiguousarray(geometry.projection_offsets_y, dtype=np.float64)
     wpc = np.ascontiguousarray(water_pre_correction if water_pre_correction is not None else [], dtype=np.float64)
     dp = C.POINTER(C.c_double)
-    o = _FdkOptions(n, nu, nv, du, dv, float(u0), float(v0), float(geometry.source_to_isocenter), float(geometry.source_to_detector),
+    o = _FdkOptions(C.sizeof(_FdkOptions), n, nu, nv, du, dv, float(u0), float(v0), float(geometry.source_to_isocenter), float(geometry.source_to_detector),
                     ang.ctypes.data_as(dp), ox.ctypes.data_as(dp), oy.ctypes.data_as(dp), int(dimension[0]), int(dimension[1]), int(dimension[2]),
                     float(spacing[0]), float(spacing[1]), float(spacing[2]),
                     *(tuple(float(v) for v in origin) if origin is not None else (float("nan"),) * 3), float(hann), float(hann_y),

@@ -183,6 +183,9 @@ int mcgpu_normalize_stack(const char *total_stack, const char *air_stack, double
  * track -> finalize (+ clear) on the device, double-buffered pinned copies, a writer thread for the files -- so the GPU
  * never waits for output.  Zero-initialise the struct; every field has a usable default. */
 typedef struct mcgpu_scan_options {
+  /* sizeof(mcgpu_scan_options) as the CALLER was compiled: fields the caller's header did not have yet read as zero (their
+   * defaults), instead of whatever follows the shorter struct in memory.  0 is refused. */
+  unsigned int struct_size;
   int mode;                                     /* MCGPU_MODE_FAST (default) or MCGPU_MODE_COMPAT */
   int first_projection, num_projections;        /* num_projections 0 = all remaining */
   unsigned long long histories_per_projection;  /* 0 = the input file's value */
@@ -301,6 +304,14 @@ int mcgpu_write_voxel_file(const char *path, const int n[3], const float spacing
  * 134 M-line text parse per process launch. */
 int mcgpu_write_voxel_binary(const char *path, const int n[3], const float spacing_cm[3], const uint8_t *material, const float *density);
 
+/* Hardware ceilings the measurement prices the FAST kernel against, measured on the context's device (about 20 ms each; SURVEY.md
+ * 8d; no reference counterpart).  MCGPU_MICROBENCH_VALU_ISSUE: out[0..2] = vector wave-instructions per ns and SIMD of a dense
+ * dependent-FMA kernel at 8 waves/SIMD with 64 active lanes, with lanes 0-31, with 32 lanes spread over the wave.
+ * MCGPU_MICROBENCH_ATOMIC_RATE: out[0] = scattered 64-bit atomic adds per second into a detector-sized (45 MB) tally. */
+#define MCGPU_MICROBENCH_VALU_ISSUE 0
+#define MCGPU_MICROBENCH_ATOMIC_RATE 1
+int mcgpu_microbench(mcgpu_ctx *ctx, int kind, double *out, int n_out);
+
 /* Device-side known-answer hooks used by the parity tests (each runs a tiny kernel on the context's device). */
 int mcgpu_kat_rng(mcgpu_ctx *ctx, int mode, int seed, int batch, int hpt, int n, float *out_f32);
 /* Raw 32-bit outputs of the FAST personality's per-history streams (no reference counterpart: the reference's RANECU,
@@ -324,6 +335,7 @@ int mcgpu_kat_f32(mcgpu_ctx *ctx, int op, int n, const float *a, const float *b,
  * windows as fractions of Nyquist (0 = plain ramp / no vertical smoothing); wpc: optional water pre-correction
  * polynomial coefficients (rtkfdk --wpc).  Displaced (half-fan) detectors are weighted automatically. */
 typedef struct mcgpu_fdk_options {
+  unsigned int struct_size;     /* sizeof(mcgpu_fdk_options) as the caller was compiled (later fields read as zero); 0 is refused */
   int n_proj, nu, nv;
   double du, dv, u0, v0;
   double sid, sdd;
@@ -337,7 +349,11 @@ typedef struct mcgpu_fdk_options {
   int n_wpc;
   int device;
   double pad;                   /* rtkfdk --pad (truncation correction; the reference passes 1.0, reconstruction.py:29,55): rows
-                                   continued on both sides by ceil(pad x width) columns, feathered point reflection; 0 = off */
+                                   continued on both sides by ceil(pad x width) columns, feathered point reflection; 0 = off.
+                                   Follows the PUBLISHED heuristic (Ohnesorge et al.) as RTK describes it; the exact extent and
+                                   weight table of rtkFFTProjectionsConvolutionImageFilter could not be checked here (RTK is not
+                                   vendored in the reference): with a truncated half-fan scan the feathered edge values fed to the
+                                   ramp may differ from rtkfdk's ("parity unpinned") */
 } mcgpu_fdk_options;
 typedef struct mcgpu_fdk_report {
   double ms_filter;      /* weight + ramp + vertical smoothing kernels */

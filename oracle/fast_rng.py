@@ -5,7 +5,7 @@ The reference has no counterpart (its generator is RANECU, K.cu:841-894, which t
 north_star names "XORWOW/Philox per lane".  The FAST kernel gives every HISTORY its own stream:
 
   Philox4x32-7( counter = {id_lo, id_hi, projection, 0x4d43475}, key = {seed, 0xCB435443} )          (Salmon et al., SC11)
-      -> x = out0 ^ out2,  c = umulhi(out1 ^ out3, a - 1) + 1     (1 <= c <= a - 1)
+      -> x = out0 ^ out2,  c = umulhi(out1 ^ out3, a - 1) + 1     (1 <= c <= a - 1; the fixed point (2^32 - 1, a - 1) is moved to c = a - 2)
   multiply-with-carry, base 2^32, lag 1, a = 4294584393:  t = a x + c;  x' = t mod 2^32;  c' = t div 2^32;  output x'
   deviate = (x' >> 8) 2^-24 + 2^-26   (never 0, never 1)
 
@@ -42,6 +42,8 @@ def seed_streams(ids, seed: int, projection: int):
                    [seed, KEY1], rounds=7)
     x = o[0] ^ o[2]
     c = (((o[1] ^ o[3]) * np.uint64(MWC_A - 1)) >> np.uint64(32)) + np.uint64(1)
+    # (2^32 - 1, a - 1) is a fixed point of the step; the seeding can produce c = a - 1 (only from the word 2^32 - 1): moved off it
+    c = np.where((x == np.uint64(MASK)) & (c == np.uint64(MWC_A - 1)), c - np.uint64(1), c)
     return x, c
 
 
@@ -76,6 +78,8 @@ def streams_python(hist: int, seed: int, projection: int, n_draws: int):
         c = [(p1 >> 32) ^ c[1] ^ k0, p1 & MASK, (p0 >> 32) ^ c[3] ^ k1, p0 & MASK]
         k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
     x, cc = c[0] ^ c[2], (((c[1] ^ c[3]) * (MWC_A - 1)) >> 32) + 1
+    if x == MASK and cc == MWC_A - 1:
+        cc -= 1
     out = []
     for _ in range(n_draws):
         t = MWC_A * x + cc

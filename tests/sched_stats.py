@@ -3,6 +3,7 @@ usage: sched_stats.py [input.in] [histories] ["tC,tR,tN,flyable_low,swap_batch" 
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MCGPU_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "4d-cbct-mc_amd", "libmcgpu_amd_stats.so"))  # the diagnostic build (stats mode)
 import cases
 eng = cases.pkg.engine
 inp = sys.argv[1] if len(sys.argv) > 1 else "/tmp/mcgpu_bench_catphan_512_894/input.in"

@@ -71,14 +71,15 @@ def test_mwc_parameters_and_seeding_range():
     m = a * 2 ** 32 - 1
     assert is_prime(m) and is_prime((m - 1) // 2)
     assert pow(2 ** 32, (m - 1) // 2, m) == 1  # b is a quadratic residue: the period is exactly a 2^31 - 1
-    # fixed points of the step: (0, 0) and (2^32 - 1, a - 1); the seeding keeps 1 <= c <= a - 2 for every Philox output
+    # fixed points of the step: (0, 0) and (2^32 - 1, a - 1)
     assert fr.mwc_step(np.uint64(0), np.uint64(0)) == (0, 0)
     x, c = fr.mwc_step(np.uint64(2 ** 32 - 1), np.uint64(a - 1))
     assert (int(x), int(c)) == (2 ** 32 - 1, a - 1)
-    assert ((2 ** 32 - 1) * (a - 2) >> 32) + 1 == a - 2  # the largest c the seeding can produce
+    # seeding: c = umulhi(w, a - 1) + 1 lies in [1, a - 1]; a - 1 only for w = 2^32 - 1, and then the fixed point is avoided explicitly
+    assert ((2 ** 32 - 1) * (a - 1) >> 32) + 1 == a - 1 and ((2 ** 32 - 2) * (a - 1) >> 32) + 1 == a - 2
     ids = np.arange(1 << 16, dtype=np.uint64)
-    _, c0 = fr.seed_streams(ids, 42, 7)
-    assert c0.min() >= 1 and c0.max() <= a - 2
+    x0, c0 = fr.seed_streams(ids, 42, 7)
+    assert c0.min() >= 1 and c0.max() <= a - 1 and not np.any((x0 == 2 ** 32 - 1) & (c0 == a - 1))
 
 
 def test_deviate_is_never_zero_or_one():

@@ -2,6 +2,7 @@
 Diagnostic (stats) build: per wave {HW_ID, XCC_ID, first/last clock (100 MHz)}; see track_pool.inc."""
 import sys, ctypes as C, collections
 ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
+__import__("os").environ.setdefault("MCGPU_AMD_LIB", __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "4d-cbct-mc_amd", "libmcgpu_amd_stats.so"))  # the diagnostic build (stats mode)
 import numpy as np, torch, cases
 eng = cases.pkg.engine
 ctx = eng.create("/tmp/mcgpu_bench_catphan_512_894/input.in", device=0)
