@@ -101,6 +101,12 @@ struct TrackCold {
   // 1 / s0_inv_w from s0_emin), float2 [mc * kS0Bins + bin]; decides most Compton angle tests without the pass that computes S0
   const float* s0_bounds;
   float s0_emin, s0_inv_w;
+  // FAST: bounds of dx / dy of a sampled source direction in the beam frame, i.e. cot(phi) at the two ends of the azimuthal
+  // aperture [phi_low, phi_low + D_phi] (MC-GPU_kernel_v1.3.cu:654-667), computed in double and drawn in by 2e-6 of the range.
+  // v_sin_f32 / v_cos_f32 are good to ~1e-6: without the clamp a few 1e-7 of the primary photons leave the aperture by up to
+  // 3e-4 detector pixels -- visible only at the half-fan beam edge, which coincides with a pixel boundary (column 1024).
+  // (-3e38, 3e38) when the aperture does not lie inside (0, pi) or differs between projections: no clamp.
+  float fan_ratio_lo, fan_ratio_hi;
   int trade_slots;  // lanes of a wave trade their parking slots: bit 0 before flying, bit 1 before the Compton and tally/source services (MCGPU_SLOT_TRADE)
 };
 

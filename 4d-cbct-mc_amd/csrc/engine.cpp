@@ -715,6 +715,22 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     for (int m = 0; m < kMaxMaterials; ++m) cold.shell_first[m] = D.shell_first[m];
     for (int k = 0; k < 3; ++k) { cold.objbox_lo[k] = D.objbox_lo[k]; cold.objbox_hi[k] = D.objbox_hi[k]; }
     cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = cold.trade_slots = -1;  // apply_schedule
+    {
+      // azimuthal aperture of the beam (the same for every projection: the pose rotates the beam frame, MC-GPU_v1.3.cu:3280-3434)
+      cold.fan_ratio_lo = -3.0e38f;
+      cold.fan_ratio_hi = 3.0e38f;
+      bool same = !H.source.empty();
+      for (const SourcePose& sp : H.source) same = same && sp.phi_low == H.source[0].phi_low && sp.D_phi == H.source[0].D_phi;
+      if (same) {
+        const double lo = (double)H.source[0].phi_low, hi = lo + (double)H.source[0].D_phi;
+        if (lo > 1.0e-3 && hi < 3.14159265358979323846 - 1.0e-3 && hi > lo) {
+          const double r_hi = std::cos(lo) / std::sin(lo), r_lo = std::cos(hi) / std::sin(hi);  // cot decreases on (0, pi)
+          const double margin = 2.0e-6 * (r_hi - r_lo);
+          cold.fan_ratio_lo = (float)(r_lo + margin);
+          cold.fan_ratio_hi = (float)(r_hi - margin);
+        }
+      }
+    }
     D.cold_host = cold;
     D.cold = D.put(std::vector<TrackCold>(1, cold));
     D.src_all = D.put(H.source);

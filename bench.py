@@ -231,7 +231,7 @@ def fast_vs_compat_check(ctx, runs=12, histories=250_000_000, projection=447):
             "passed": bool(np.all(np.abs(z) < 6.0) and (known is None or known["passed"]))}  # Student t with 2 runs - 2 = 22 degrees of freedom: P(|t| > 6) = 5e-6 per class
 
 
-def entry_face_deficit(ctx, runs=8, histories=250_000_000, projection=600):
+def entry_face_deficit(ctx, runs=8, histories=1_000_000_000, projection=600):
     """KNOWN DEVIATION 2: the reference puts an entering photon EPS_SOURCE = 1.5e-5 cm past the entry face ALONG ITS
     RAY and calls everything within EPS_SOURCE of a face "outside" (MC-GPU_kernel_v1.3.cu:714-805, 1036-1042), so at oblique
     projections a first Woodcock step shorter than ~1.6e-5 cm is tallied at once as an un-attenuated primary: 5-7e-6 of the
