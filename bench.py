@@ -351,7 +351,7 @@ def roofline_block(workload, H, k_ms, ceilings=None):
         insts = pmc["SQ_INSTS_VALU"]["mean_per_dispatch"]
         if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
             l2_hit = pmc["TCC_HIT_sum"]["mean_per_dispatch"] / max(pmc["TCC_HIT_sum"]["mean_per_dispatch"] + pmc["TCC_MISS_sum"]["mean_per_dispatch"], 1.0)
-        # ceiling: a dense dependent-FMA kernel, 8 waves/SIMD, 16-32 active lanes, on the same chip (tools/micro/exec_skip.hip:
+        # ceiling: a dense dependent-FMA kernel, 8 waves/SIMD, 16-32 active lanes, on the same chip (tools/archive/micro/exec_skip.hip:
         # 5.24e9 wave-instructions on 1024 SIMDs in 5.1 ms)
         # measured in this run when `ceilings` is given (the higher of the half-populated masks: the conservative peak); else the
         # builder-run figure of round 3 (5.24e9 wave-instructions on 1024 SIMDs in 5.1 ms)
@@ -359,7 +359,7 @@ def roofline_block(workload, H, k_ms, ceilings=None):
             cv = ceilings["valu_wave_instructions_per_ns_per_simd"]
             peak, peak_src = max(cv["lanes_0_31"], cv["32_lanes_spread"], cv["64_active_lanes"]), "measured in this run (mcgpu_microbench)"
         else:
-            peak, peak_src = 5.24e9 / 1024.0 / 5.1e6, "tools/micro/exec_skip.hip, round 3"
+            peak, peak_src = 5.24e9 / 1024.0 / 5.1e6, "tools/archive/micro/exec_skip.hip, round 3"
         lane_util = pmc["SQ_THREAD_CYCLES_VALU"]["mean_per_dispatch"] / pmc["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / 64.0
         valu = {"valu_wave_instructions_per_launch": insts, "valu_wave_instructions_per_history": insts / H,
                 "achieved_per_ns_per_simd": insts / 1024.0 / (k_ms * 1e6),
@@ -912,11 +912,11 @@ def main():
             base, img_cpu, w2_cpu, n_cpu = cpu_baseline(ctx)
             out["cpu_baseline"] = base
             # a second ceiling: one scattered 64-bit atomic add per detected photon; rate measured by
-            # tools/micro/atomic_rate.hip on MI355X = 2.37e10/s
+            # tools/archive/micro/atomic_rate.hip on MI355X = 2.37e10/s
             tally_hits = base["events_per_history"]["tally_hits"]
-            a_peak = ceilings["scattered_64bit_atomic_adds_per_s"] / 1e9 if ceilings else 23.7  # 23.7: tools/micro/atomic_rate.hip, round 2
+            a_peak = ceilings["scattered_64bit_atomic_adds_per_s"] / 1e9 if ceilings else 23.7  # 23.7: tools/archive/micro/atomic_rate.hip, round 2
             out["atomic_roofline"] = {"bound": "scattered 64-bit atomic adds", "achieved": tally_hits * H / (k_ms * 1e-3) / 1e9, "peak": a_peak,
-                                      "peak_source": "measured in this run (mcgpu_microbench)" if ceilings else "tools/micro/atomic_rate.hip, round 2",
+                                      "peak_source": "measured in this run (mcgpu_microbench)" if ceilings else "tools/archive/micro/atomic_rate.hip, round 2",
                                       "unit": "Gatomic/s", "frac": tally_hits * H / (k_ms * 1e-3) / (a_peak * 1e9),
                                       "detected_photons_per_history": tally_hits}
             out["check"].update(oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu))

@@ -277,7 +277,7 @@ def test_mc_scan_to_fdk_round_trip(engine, tmp_path):
 
     ref = phantom_on_grid(xi, -zi, -yi)
     cc = np.corrcoef(ref.ravel(), vol.ravel())[0, 1]
-    assert cc > 0.85, cc  # noisy scan (1.5e7 histories per projection); tools/mc_to_recon.py reaches 0.96 with more
+    assert cc > 0.85, cc  # noisy scan (1.5e7 histories per projection); tools/archive/mc_to_recon.py reaches 0.96 with more
     central = (np.abs(yi) < 40) & (xi ** 2 + zi ** 2 < 110 ** 2)
     water, rod, air_hole = [vol[central & (ref > lo) & (ref < hi)].mean() for lo, hi in ((0.99, 1.01), (1.5, 1.7), (-1, 0.01))]
     assert 0.015 < water < 0.022 and rod > 1.4 * water and air_hole < 0.25 * water, (water, rod, air_hole)
