@@ -28,7 +28,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kIntegerDigits = 11;                          // values below 1e11 (engine.cpp sizes the buffers for that)
+constexpr int kIntegerDigits = 11;                          // values below 1e11 (engine.cpp: mcgpu_format_projection sizes the buffers for that)
 constexpr unsigned long long kIntegerLimit = 100000000000ULL;
 constexpr int kLineMax = 4 * (kIntegerDigits + 9) + 4;      // 4 numbers "i.ffffffff", 3 blanks, newline
 

@@ -1,4 +1,4 @@
-// geometry_device.hpp -- interface of the on-device geometry rebuild (geometry_device.hip), used by engine.cpp.
+// geometry_device.hpp -- interface of the on-device geometry rebuild (geometry_device.hip), used by model_device.cpp and engine_geometry.cpp.
 #pragma once
 #include <hip/hip_runtime.h>
 

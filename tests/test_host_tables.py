@@ -121,7 +121,7 @@ def test_bench_size_cirs_tables_equal_the_reference_parse(engine, tmp_path):
 
 
 def test_s0_bounds_bracket_the_reference_arithmetic(engine, case_dir):
-    """The COMPAT kernel decides the Compton angle test from bounds lo <= S0 <= hi (engine.cpp: build_s0_bounds) and rejects
+    """The COMPAT kernel decides the Compton angle test from bounds lo <= S0 <= hi (model_device.cpp: build_s0_bounds) and rejects
     without a pass over the shells when xi lo > hi T(tau), which also needs S(theta) <= hi.  Both facts are held here against
     the reference's own float arithmetic (the oracle's, libm and portable math) for every material: at random energies, at the
     energies next to every bin edge, and for random deflections; the smallest slack is reported with the assertion."""
