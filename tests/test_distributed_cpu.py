@@ -189,3 +189,14 @@ def test_bench_refuses_a_rank_count_it_cannot_honour():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode != 0 and r.stdout.strip() == "" and "refusing to run a mislabelled measurement" in r.stderr
+
+
+def test_bench_adopts_the_launchers_world_size_when_gpus_is_not_given():
+    """`torchrun ... bench.py` WITHOUT --gpus: the launcher's WORLD_SIZE is the GPU count; the run then stops where
+    every GPU-less run stops -- at "needs a GPU" -- and not at the mislabelled-measurement refusal."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"],
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "mislabelled" not in r.stderr and "needs a GPU" in r.stderr, r.stderr[-500:]

@@ -259,6 +259,31 @@ def test_mpirun_shim_translates_the_reference_command_line(tmp_path):
     assert run("--tag-output", "-v", "-n", "4", "/bin/echo", "in") == "in --gpus 4"
 
 
+def test_option_structs_carry_their_size(engine, case_dir):
+    """mcgpu_scan_options / mcgpu_fdk_options begin with `struct_size`: a caller that forgot to set it is refused (its fields would
+    otherwise be read at the wrong offsets), one that was compiled against a SHORTER struct gets the defaults of the fields it does
+    not know -- here a scan-options struct cut before `shard`, handed to a host-only context, fails for the right reason (no
+    device), not for a garbage shard mode."""
+    import ctypes as C
+    lib = engine.load_library()
+    with engine.create(case_dir("air"), device=-1) as ctx:
+        o = engine.ScanOptions()
+        r = engine.ScanReport()
+        assert lib.mcgpu_run_scan(ctx.h, C.byref(o), C.byref(r)) != 0
+        assert b"struct_size" in lib.mcgpu_last_error()
+        short = engine.ScanOptions.shard.offset
+        o.struct_size = short
+        o.shard, o.projection_stride, o.projection_phase = 77, -5, 99  # beyond struct_size: must not be looked at
+        assert lib.mcgpu_run_scan(ctx.h, C.byref(o), C.byref(r)) != 0
+        msg = lib.mcgpu_last_error().decode()
+        assert "no device" in msg and "projection_phase" not in msg, msg
+    recon = __import__("cases").pkg.reconstruction
+    fo = recon._FdkOptions()
+    lib.mcgpu_fdk_reconstruct.restype = C.c_int
+    assert lib.mcgpu_fdk_reconstruct(C.byref(fo), None, None, None) != 0
+    assert b"struct_size" in lib.mcgpu_last_error()
+
+
 def test_clone_shares_the_parsed_model(engine, case_dir):
     """mcgpu_clone: a further context of the same simulation without parsing anything again (one per device in the
     executable's --gpus path); host tables and configuration are those of the parsed context, and it outlives it."""

@@ -247,6 +247,40 @@ def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_
 
 
 @pytest.mark.gpu
+def test_scan_sharded_by_projection_equals_single_context(engine, case_dir, tmp_path):
+    """mcgpu_run_scan_multi with MCGPU_SHARD_PROJECTIONS (SURVEY 8e's fallback): three contexts, each simulating whole projections
+    on its own pipeline thread, shared stacks filled by slice index; and the building block it is made of -- one plain
+    mcgpu_run_scan per context with projection_stride / projection_phase into caller-owned stacks.  Stacks equal the
+    single-context scan bit for bit in both personalities."""
+    for mode, hist in (("fast", 400_000), ("compat", 19200 * 5)):
+        ref_dir, out = tmp_path / f"{mode}_one", tmp_path / f"{mode}_three"
+        ref_dir.mkdir(); out.mkdir()
+        with engine.create(case_dir("catphan64_ct"), device=0) as c:
+            c.run_scan(mode=mode, histories=hist, crop_nx=128, output_folder=ref_dir)
+        ctxs = [engine.create(case_dir("catphan64_ct"), device=0) for _ in range(3)]
+        try:
+            rep = ctxs[0].run_scan(mode=mode, histories=hist, crop_nx=128, output_folder=out, peers=ctxs[1:], shard="projections")
+            assert rep["projections"] == 4
+        finally:
+            for c in ctxs:
+                c.close()
+        for m in ("total", "unscattered", "scattered"):
+            assert np.array_equal(engine.stack_read(ref_dir / f"projections_{m}.mha"), engine.stack_read(out / f"projections_{m}.mha")), (mode, m)
+
+
+@pytest.mark.gpu
+def test_microbench_reports_plausible_ceilings(engine, case_dir):
+    """mcgpu_microbench: the ceilings bench.py quotes are measured, positive and in the range the part can deliver (an MI355X issues
+    between 0.4 and 1.3 vector wave-instructions per ns and SIMD, and a few 1e10 scattered atomics per second)."""
+    with engine.create(case_dir("air"), device=0) as ctx:
+        v = ctx.microbench("valu_issue")
+        a = ctx.microbench("atomic_rate")
+    assert len(v) == 3 and all(0.4 < x < 1.3 for x in v), v
+    assert v[1] >= 0.95 * v[0]  # half the lanes idle never issues slower
+    assert 5e9 < a < 1e11, a
+
+
+@pytest.mark.gpu
 def test_device_formatted_projection_file_is_byte_identical(engine, case_dir, tmp_path):
     """The data lines formatted on the device ("%.8lf" by exact integer arithmetic, ascii_device.hip) against the host writer
     (itself byte-identical to the reference's report_image on the data lines): random tallies over many magnitudes, zeros, the
