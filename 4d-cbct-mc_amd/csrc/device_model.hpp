@@ -41,6 +41,24 @@ __host__ __device__
 inline unsigned int tiled_voxel(unsigned int ix, unsigned int iy, unsigned int iz, unsigned int sub_nx, unsigned int sub_nxy) {
   return ((((ix >> 2) + (iy >> 2) * sub_nx + (iz >> 2) * sub_nxy)) << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u);
 }
+// Second level of a u8 volume as 16-byte TILE RECORDS (FAST kernel, round 4): the voxels of a 4x4x4 tile take at most two palette
+// entries a, b (a material boundary) in all but a few tiles: voxel v (bit (iz&3) 16 + (iy&3) 4 + (ix&3) of `mask`) is b where the
+// bit is set, else a; kind != 0: three or more entries -- ask the tiled volume.  A flight step into a mixed brick reads the tile's
+// record INSTEAD of the voxel byte: the set of cache lines such steps touch is every tile of every mixed brick (thorax: 78 % of
+// the tissue voxels, 22 MB of 64-byte tiles against 4 MB of L2 per XCD), and at 16 bytes per tile it is a quarter of that.
+// Records of the 2x2x2 tiles of an 8^3-voxel cube are contiguous (one 128-byte line).
+struct TileRecord {
+  unsigned int ab;             // a | b << 8
+  unsigned int kind;           // 0: mask valid, 1: read the voxel byte
+  unsigned long long mask;
+};
+static_assert(sizeof(TileRecord) == 16, "one record = 16 bytes, eight per 128-byte line");
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned int tile_record_index(unsigned int tx, unsigned int ty, unsigned int tz, unsigned int rec_nx, unsigned int rec_nxy) {
+  return ((((tx >> 1) + (ty >> 1) * rec_nx + (tz >> 1) * rec_nxy)) << 3) | ((tz & 1u) << 2) | ((ty & 1u) << 1) | (tx & 1u);
+}
 constexpr int kTrackBlockThreads = 512;   // COMPAT kernel: 8 waves per workgroup
 constexpr int kPoolBlockThreads = 1024;   // FAST kernel: 16 waves per workgroup, two workgroups (8 waves/SIMD) per CU share two brick grids
 constexpr int kPoolParked = 1;            // FAST kernel: histories a lane parks in LDS slots beside the one in its registers
@@ -116,8 +134,10 @@ struct TrackArgs {
   const float* palette;  // float2 pairs {density, bits(mat_c)}
   int vol_kind, palette_size;
   int brick_shift, brick_nx, brick_nxy, brick_bytes;
-  const unsigned char* sub;  // FAST: second-level codes, 4 bits per 4^3-voxel sub-brick, dense (null: none)
+  const unsigned char* sub;  // FAST: second level, dense over the 4^3-voxel tiles (null: none): 4-bit codes, or TileRecord[] (sub_kind 2)
   int sub_nx, sub_nxy;
+  int sub_kind;              // host-side dispatch only: 0 none, 1 four-bit codes, 2 tile records
+  int rec_nx, rec_nxy;       // tile records: cubes of 2x2x2 tiles per row / per slab (tile_record_index)
   int nx, ny, nz, nxy;
   float inv_vs[3];
   float bbox[3];

@@ -90,6 +90,8 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "bricks_exterior") *value = ctx->dev.bricks_exterior;
   else if (k == "sub_bricks") *value = (long long)ctx->dev.sub_n[0] * ctx->dev.sub_n[1] * ctx->dev.sub_n[2];
   else if (k == "sub_bricks_mixed") *value = ctx->dev.sub_mixed;
+  else if (k == "tile_records") *value = ctx->dev.tile_rec ? 1 : 0;
+  else if (k == "tiles_in_mixed_bricks") *value = ctx->dev.tiles_in_mixed_bricks;
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
   else if (k == "sigma_bracket_shift") *value = ctx->dev.sig_shift;

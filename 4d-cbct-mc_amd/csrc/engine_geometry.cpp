@@ -147,6 +147,8 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
   g.idx = (unsigned char*)D.vol;
   g.sub_first = D.sub_first; g.brick_first = D.brick_first;
   g.sub = D.sub; g.bricks = D.bricks; g.code_of = D.code_of_dev; g.background = D.background;
+  g.rec = D.tile_rec;
+  for (int k = 0; k < 3; ++k) g.rn[k] = D.rec_n[k];
   g.out = D.rebuild_out;
   const bool allow_exterior = !D.knobs.no_exterior;
   HIP_TRY(launch_geometry_rebuild(g, frame, allow_exterior, nullptr));

@@ -82,6 +82,9 @@ struct DeviceModel {
   int background = 0;
   unsigned char* sub = nullptr;   // second-level codes: 4 bits per sub-brick of 4^3 voxels, dense over the volume (u8 volumes)
   int sub_n[3] = {1, 1, 1}, sub_mixed = 0;
+  TileRecord* tile_rec = nullptr;  // second level as 16-byte records of the tiles (MCGPU_TILE_RECORDS; device_model.hpp), or null
+  int rec_n[3] = {1, 1, 1};        // cubes of 2x2x2 tiles per axis
+  long long tiles_in_mixed_bricks = 0;  // tiles a flight step can ask the second level / the volume for (hot set of the voxel gathers)
   int brick_shift = 0, brick_n[3] = {1, 1, 1}, brick_count = 0, brick_bytes = 0, bricks_mixed = 0;
   int brick_palette[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int has_exterior = 0, bricks_exterior = 0;

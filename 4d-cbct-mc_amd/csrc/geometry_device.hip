@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void classify_sub_kernel(GeometryRebuild g) {
     const int sx = s % g.sn[0], sy = (s / g.sn[0]) % g.sn[1], sz = s / (g.sn[0] * g.sn[1]);
     const int x0 = sx << 2, y0 = sy << 2, z0 = sz << 2;
     const int x1 = min(x0 + 4, g.nx), y1 = min(y0 + 4, g.ny), z1 = min(z0 + 4, g.nz);
-    int first = -1;
-    bool mixed = false;
+    int first = -1, second = -1;
+    bool mixed = false, many = false;
+    unsigned long long mask = 0ULL;  // tile record: voxels that hold the tile's second palette entry
     const unsigned char* tile = g.idx + ((size_t)s << 6);  // the sub-brick's own 64-byte tile
     for (int z = z0; z < z1; ++z)
       for (int y = y0; y < y1; ++y) {
@@ -88,11 +89,23 @@ __global__ __launch_bounds__(256) void classify_sub_kernel(GeometryRebuild g) {
         for (int x = x0; x < x1; ++x) {
           const int v = row[x];
           if (first < 0) first = v;
-          else if (v != first) mixed = true;
+          else if (v != first) {
+            mixed = true;
+            if (second < 0) second = v;
+            if (v == second) mask |= 1ULL << (((z & 3) << 4) | ((y & 3) << 2) | (x & 3));
+            else many = true;
+          }
           atomicOr(&seen[v >> 5], 1u << (v & 31));
         }
       }
     g.sub_first[s] = mixed ? kMixed : (unsigned short)first;
+    if (g.rec) {
+      TileRecord r;
+      r.ab = (unsigned int)(first < 0 ? 0 : first) | ((unsigned int)(second < 0 ? (first < 0 ? 0 : first) : second) << 8);
+      r.kind = many ? 1u : 0u;
+      r.mask = many ? 0ULL : mask;
+      g.rec[tile_record_index((unsigned int)sx, (unsigned int)sy, (unsigned int)sz, (unsigned int)g.rn[0], (unsigned int)(g.rn[0] * g.rn[1]))] = r;
+    }
   }
   __syncthreads();
   if (threadIdx.x < 8 && seen[threadIdx.x] != 0u) atomicOr(&g.out[threadIdx.x], seen[threadIdx.x]);

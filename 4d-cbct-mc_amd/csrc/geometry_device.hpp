@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "device_model.hpp"
+
 namespace mcgpu {
 
 struct GeometryRebuild {
@@ -15,6 +17,8 @@ struct GeometryRebuild {
   unsigned short* sub_first;        // scratch [sub-bricks]: palette entry or 0x100 = mixed
   unsigned short* brick_first;      // scratch [bricks]
   unsigned char* sub;               // 4-bit codes of the sub-bricks, two per byte (null: level not in use)
+  TileRecord* rec;                  // 16-byte records of the tiles (device_model.hpp; null: not in use)
+  int rn[3];                        // cubes of 2x2x2 tiles per axis (tile_record_index)
   unsigned char* bricks;            // 4-bit codes of the bricks, two per byte
   const unsigned char* code_of;     // [256] palette entry -> 4-bit code (0xF: not among the 14 coded entries)
   int background;                   // palette entry of the homogeneous background (outside the object box)

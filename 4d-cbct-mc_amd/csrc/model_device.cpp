@@ -341,6 +341,43 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       }
       D.sub = off ? nullptr : D.put(sub);
     }
+    {
+      // Tile records (device_model.hpp: TileRecord): the hot set of the voxel gathers is every 64-byte tile of every MIXED brick.
+      // Where that set is far beyond the L2 (4 MB per XCD) -- body-filling tissue volumes: thorax 22 MB -- the launch is bound by
+      // the line fills of those gathers (profiles/r04p_*: ONE more cold line per mixed step doubles the thorax's kernel time, one
+      // more load from the SAME line costs 2 %), and the records shrink the set fourfold.  MCGPU_TILE_RECORDS=0/1 overrides.
+      long long hot_tiles = 0;
+      for (size_t b = 0; b < nsub; ++b) {
+        const int bx = (int)((b % D.sub_n[0]) << 2) >> k, by = (int)(((b / D.sub_n[0]) % D.sub_n[1]) << 2) >> k, bz = (int)((b / ((size_t)D.sub_n[0] * D.sub_n[1])) << 2) >> k;
+        hot_tiles += mixed[((size_t)bz * D.brick_n[1] + by) * D.brick_n[0] + bx] ? 1 : 0;
+      }
+      D.tiles_in_mixed_bricks = hot_tiles;
+      const char* knob = getenv("MCGPU_TILE_RECORDS");
+      const bool on = knob ? atoi(knob) != 0 : hot_tiles * 64 > (8LL << 20);
+      D.rec_n[0] = (D.sub_n[0] + 1) >> 1; D.rec_n[1] = (D.sub_n[1] + 1) >> 1; D.rec_n[2] = (D.sub_n[2] + 1) >> 1;
+      D.tile_rec = nullptr;
+      if (on) {
+        std::vector<TileRecord> rec((size_t)D.rec_n[0] * D.rec_n[1] * D.rec_n[2] * 8, TileRecord{0u, 0u, 0ULL});
+        for (size_t t = 0; t < nsub; ++t) {
+          const unsigned int tx = (unsigned int)(t % D.sub_n[0]), ty = (unsigned int)((t / D.sub_n[0]) % D.sub_n[1]), tz = (unsigned int)(t / ((size_t)D.sub_n[0] * D.sub_n[1]));
+          TileRecord r{0u, 0u, 0ULL};
+          int a = -1, b2 = -1;
+          for (int v = 0; v < 64 && r.kind == 0u; ++v) {
+            const int x = (int)(tx << 2) + (v & 3), y = (int)(ty << 2) + ((v >> 2) & 3), z = (int)(tz << 2) + (v >> 4);
+            if (x >= nx || y >= ny || z >= nz) continue;  // padding of an edge tile: never addressed
+            const int e = idx8[((size_t)z * ny + y) * nx + x];
+            if (a < 0) a = e;
+            if (e == a) continue;
+            if (b2 < 0) b2 = e;
+            if (e == b2) r.mask |= 1ULL << v;
+            else r.kind = 1u;
+          }
+          r.ab = (unsigned int)(a < 0 ? 0 : a) | ((unsigned int)(b2 < 0 ? (a < 0 ? 0 : a) : b2) << 8);
+          rec[tile_record_index(tx, ty, tz, (unsigned int)D.rec_n[0], (unsigned int)(D.rec_n[0] * D.rec_n[1]))] = r;
+        }
+        D.tile_rec = D.put(rec);
+      }
+    }
   } else {
     D.vol_kind = kVolU16;
     D.vol = D.put(idx16);
@@ -580,6 +617,9 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.brick_shift = D.brick_shift; A.brick_nx = D.brick_n[0]; A.brick_nxy = D.brick_n[0] * D.brick_n[1];
   A.brick_bytes = D.vol_kind == kVolU8 ? D.brick_bytes : 0;
   A.sub = D.vol_kind == kVolU8 ? D.sub : nullptr; A.sub_nx = D.sub_n[0]; A.sub_nxy = D.sub_n[0] * D.sub_n[1];
+  A.sub_kind = A.sub ? 1 : 0;
+  A.rec_nx = D.rec_n[0]; A.rec_nxy = D.rec_n[0] * D.rec_n[1];
+  if (D.vol_kind == kVolU8 && D.tile_rec) { A.sub = reinterpret_cast<const unsigned char*>(D.tile_rec); A.sub_kind = 2; }  // the records win over the code table
   A.lds = D.lds;
   A.nx = H.voxels.n[0]; A.ny = H.voxels.n[1]; A.nz = H.voxels.n[2]; A.nxy = A.nx * A.ny;
   for (int k = 0; k < 3; ++k) {

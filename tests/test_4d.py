@@ -108,11 +108,13 @@ def test_gpu_warp_equals_torch_grid_sample_fixture(engine, case_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cirs76", "slab4d"])
-def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, case):
-    """mcgpu_warp_geometry (index volume warped, both brick levels, object box and Woodcock majorant rebuilt on the device)
-    against the route through the host: warp in the MCGeometry frame (tests/warp_ref.py, pinned by the torch fixture), a
-    fresh context on the warped voxel file.  Same host tables, same COMPAT tallies bit for bit, same FAST tallies."""
+@pytest.mark.parametrize("case,records", [("cirs76", "0"), ("cirs76", "1"), ("slab4d", "0"), ("slab4d", "1")])
+def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, monkeypatch, case, records):
+    """mcgpu_warp_geometry (index volume warped, both brick levels -- with `records`, the 16-byte tile records rebuilt by the
+    classify kernel --, object box and Woodcock majorant rebuilt on the device) against the route through the host: warp in the
+    MCGeometry frame (tests/warp_ref.py, pinned by the torch fixture), a fresh context on the warped voxel file.  Same host
+    tables, same COMPAT tallies bit for bit, same FAST tallies."""
+    monkeypatch.setenv("MCGPU_TILE_RECORDS", records)
     mats, spc = cases.material_files(), cases.spectrum_file()
     if case == "cirs76":
         g = cases.CASES["cirs76"][0]()

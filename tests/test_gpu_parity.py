@@ -267,9 +267,10 @@ def test_fast_image_is_independent_of_slot_trading_segment_rule_and_brick_levels
     for no_exterior in (False, True):
         if no_exterior:
             monkeypatch.setenv("MCGPU_NO_EXTERIOR", "1")
-        for sub in ("0", "1"):
+        for sub in ("0", "1", "records"):  # second level off / 4-bit codes / 16-byte tile records (MCGPU_TILE_RECORDS)
             for max_bricks in ((None, "300", "40") if no_exterior else (None,)):
-                monkeypatch.setenv("MCGPU_SUB_BRICKS", sub)
+                monkeypatch.setenv("MCGPU_SUB_BRICKS", "1" if sub == "1" else "0")
+                monkeypatch.setenv("MCGPU_TILE_RECORDS", "1" if sub == "records" else "0")
                 if max_bricks:
                     monkeypatch.setenv("MCGPU_MAX_BRICKS", max_bricks)
                 else:
@@ -278,6 +279,7 @@ def test_fast_image_is_independent_of_slot_trading_segment_rule_and_brick_levels
                     assert (ctx.geti("bricks_exterior") == 0) == no_exterior
                     if max_bricks:
                         assert ctx.geti("brick_count") <= int(max_bricks)
+                    assert ctx.geti("tile_records") == (1 if sub == "records" else 0)
                     img = ctx.run_projection(p, n, mode="fast", seed=21)[0]
                     if no_exterior:
                         seen.add((ctx.geti("brick_shift"), ctx.geti("bricks_mixed"), ctx.geti("sub_bricks_mixed")))
