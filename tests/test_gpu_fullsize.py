@@ -40,6 +40,14 @@ def thorax512(engine, tmp_path_factory):
         yield ctx
 
 
+def test_second_level_is_chosen_by_the_hot_set(catphan512, thorax512):
+    """The 16-byte tile records (MCGPU_TILE_RECORDS) are on by default exactly where the tiles of the mixed bricks -- the cache lines
+    the voxel gathers of the flight step touch -- exceed 8 MiB: the tissue-filled thorax (25 MiB), not the Catphan (2.7 MiB).  The
+    statistical FAST tests of this file therefore exercise both lookups at full size."""
+    assert catphan512.geti("tile_records") == 0 and catphan512.geti("tiles_in_mixed_bricks") * 64 < (8 << 20)
+    assert thorax512.geti("tile_records") == 1 and thorax512.geti("tiles_in_mixed_bricks") * 64 > (8 << 20)
+
+
 def test_bench_shape_is_what_baseline_names(catphan512):
     ctx = catphan512
     assert (ctx.geti("num_voxels_x"), ctx.geti("num_voxels_y"), ctx.geti("num_voxels_z")) == (512, 512, 512)
