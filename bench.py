@@ -336,7 +336,7 @@ def measured_ceilings(ctx):
             "scattered_64bit_atomic_adds_per_s": ctx.microbench("atomic_rate"), "source": "mcgpu_microbench in this run"}
 
 
-def roofline_block(workload, H, k_ms, ceilings=None):
+def roofline_block(workload, H, k_ms, ceilings=None, ctx=None):
     """`roofline` object of one workload: algorithmic bytes of the reference layout over the measured kernel time, plus the
     PMC-counter traffic of this kernel build when a stamped summary of it is committed."""
     label, algo_bytes, algo_src = WORKLOADS[workload]
@@ -368,7 +368,8 @@ def roofline_block(workload, H, k_ms, ceilings=None):
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "hbm_counter_frac": hbm_counter_frac, "traffic_source": pmc_src,
             "fabric_bytes_per_history": None if traffic is None else traffic / H, "l2_hit_rate": l2_hit,
-            "kernel": "track_pool_kernel<u8> (fast)", "kernel_ms_avg": k_ms, "kernel_source_sha16": kernel_source_hash(),
+            "kernel": "track_pool_kernel<4> (fast, u8 volume + tile records)" if (ctx is not None and ctx.geti("tile_records")) else "track_pool_kernel<0> (fast, u8 volume)",
+            "kernel_ms_avg": k_ms, "kernel_source_sha16": kernel_source_hash(),
             "algorithmic_bytes_per_history": algo_bytes, "algorithmic_bytes_source": algo_src,
             "algorithmic_bytes_per_launch": algo_bytes * H}
     if valu:
@@ -448,9 +449,9 @@ def other_workloads(eng, torch, H, projections, device, ceilings=None):
         t1 = time.perf_counter()
         with eng.create(inp, device=device) as c2:
             k_ms, k_min, detected = timed_launches(c2, torch, H)
-            roof, valu = roofline_block(wl, H, k_ms, ceilings)
+            roof, valu = roofline_block(wl, H, k_ms, ceilings, c2)
             out[wl] = {"value": H / (k_ms * 1e-3), "unit": "histories/s", "kernel_ms_avg": k_ms, "kernel_ms_min": k_min, "launches": 8,
-                       "config": WORKLOADS[wl][0], "roofline": {k: roof[k] for k in ("frac", "achieved", "traffic", "hbm_counter_frac", "fabric_bytes_per_history",
+                       "config": WORKLOADS[wl][0], "roofline": {k: roof[k] for k in ("kernel", "frac", "achieved", "traffic", "hbm_counter_frac", "fabric_bytes_per_history",
                                                                                      "l2_hit_rate", "traffic_source", "algorithmic_bytes_per_history")},
                        "valu_issue": valu, "volume_bytes": c2.geti("volume_bytes_device"), "materials_used": c2.geti("num_materials_used"),
                        "detected_energy_units_last_projection": detected,
@@ -834,7 +835,7 @@ def main():
         value = total_hist / elapsed
         k_ms = float(np.mean(kernel_ms))
         ceilings = measured_ceilings(ctx) if world == 1 else None
-        roof, valu = roofline_block(args.workload, H, k_ms, ceilings)
+        roof, valu = roofline_block(args.workload, H, k_ms, ceilings, ctx)
         out = {
             "metric": "photon histories/sec (512^3 vol, 894 proj)", "value": value, "unit": "histories/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
