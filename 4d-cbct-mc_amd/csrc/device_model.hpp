@@ -65,6 +65,7 @@ constexpr int kPoolParked = 1;            // FAST kernel: histories a lane parks
 constexpr int kPoolWavesPerSimd = 2 * kPoolBlockThreads / 64 / 4;  // two workgroups per CU (each gets half of the 160 KB of LDS)
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)
+constexpr int kWoodShift = 6;             // FAST: coarse Woodcock bins of 64 table bins (320 eV): 376 floats of LDS
 constexpr int kSlotWords = 12;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kS0Bins = 1024;            // COMPAT: energy bins of the S0 bounds (TrackCold::s0_bounds)
 constexpr int kNumStats = 32;             // scheduler counters of the diagnostic build
@@ -84,6 +85,11 @@ struct LdsLayout {
   // FAST kernel only: brackets of the total cross section per (coarse energy bin, material), TrackArgs::sig_shift >= 0
   int sig_mid;               // fp16[ncoarse * nmat]: centre of [min, max] of mfp_tot over the coarse bin
   int sig_w;                 // float[ncoarse]: relative half width that covers every material of the bin
+  // FAST kernel only: the Woodcock majorant mean free path per COARSE energy bin of 2^kWoodShift table bins = the smallest value
+  // the reference's table (MC-GPU_kernel_v1.3.cu:228) takes anywhere in the bin.  Delta tracking is exact for any majorant, so
+  // a history may use the coarse one (a few % more virtual interactions at low energies) and the kernel needs no table fetch from
+  // memory when a Compton event or a new photon changes the energy: one dependent round trip fewer per service batch.
+  int wood;                  // float[ceil(num_values / 2^kWoodShift)]
   int total;                 // bytes
 };
 
@@ -103,6 +109,7 @@ struct TrackCold {
   const unsigned char* bricks;  // brick grid, two 4-bit codes per byte (u8 volumes only)
   const unsigned short* sig_mid;  // staging sources of LdsLayout::sig_mid / sig_w (null when the brackets are off)
   const float* sig_w;
+  const float* wood_coarse;       // staging source of LdsLayout::wood
   int brick_palette[16];        // palette index of brick code c (c < 15)
   // dose tallies (K.cu:418-443, :1547-1563); buffers live for the whole simulation (all projections accumulate)
   unsigned long long* dose_voxels;     // ulonglong2 {Edep * 100, Edep^2} per ROI voxel, x fastest; null = tally off

@@ -168,6 +168,8 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
     std::vector<float> wood(2 * (size_t)H.mat.num_values);
     for (int i = 0; i < H.mat.num_values; ++i) { wood[2 * i] = H.mat.woodcock[i].x; wood[2 * i + 1] = H.mat.woodcock[i].y; }
     HIP_TRY(hipMemcpy(D.woodcock, wood.data(), wood.size() * 4, hipMemcpyHostToDevice));
+    const std::vector<float> coarse = coarse_woodcock(H);  // the FAST kernel's LDS copy of the majorant follows the table
+    HIP_TRY(hipMemcpy(D.wood_coarse, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
   }
   D.bricks_mixed = (int)out[14]; D.bricks_exterior = (int)out[15]; D.sub_mixed = (int)out[16];
   const int had_exterior = D.has_exterior;

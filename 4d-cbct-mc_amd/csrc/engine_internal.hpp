@@ -105,6 +105,7 @@ struct DeviceModel {
   unsigned long long* work_counter = nullptr;  // history-id dispenser of the FAST kernel
   unsigned long long* scratch_image = nullptr;  // device tally of mcgpu_run_projection (allocated on first use)
   float *woodcock = nullptr, *mfp = nullptr, *mfp_tot = nullptr;
+  float* wood_coarse = nullptr;  // FAST: majorant per coarse energy bin (LdsLayout::wood), rebuilt with the Woodcock table
   unsigned short* sig_mid = nullptr;  // cross-section brackets (FAST flight step), see upload_model
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
@@ -176,6 +177,7 @@ struct mcgpu_ctx {
 
 namespace mcgpu {
 // model_device.cpp
+std::vector<float> coarse_woodcock(const HostModel& H);  // LdsLayout::wood from the host's Woodcock table
 void read_env_knobs(DeviceModel& D);
 void apply_schedule(DeviceModel& D);
 void upload_model(mcgpu_ctx& C, int device_id);

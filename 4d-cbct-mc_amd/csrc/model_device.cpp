@@ -4,6 +4,24 @@
 
 namespace mcgpu {
 
+// Majorant mean free path per coarse energy bin (device_model.hpp: LdsLayout::wood): the table is piecewise linear, mfp(E) =
+// x_i + E y_i on table bin i, so its minimum over a coarse bin is taken at the ends of its table bins.  One part in 1e6 below that,
+// so that the float product the kernel forms (mfp x density x sigma) stays a probability.
+std::vector<float> coarse_woodcock(const HostModel& H) {
+  const int nv = H.mat.num_values, nc = (nv + (1 << kWoodShift) - 1) >> kWoodShift;
+  const double e0 = (double)H.mat.e0, de = 1.0 / (double)H.mat.ide;
+  std::vector<float> out((size_t)nc, 0.f);
+  for (int c = 0; c < nc; ++c) {
+    double lo = 1.0e30;
+    for (int i = c << kWoodShift; i < std::min(nv, (c + 1) << kWoodShift); ++i) {
+      const double x = (double)H.mat.woodcock[i].x, y = (double)H.mat.woodcock[i].y;
+      lo = std::min(lo, std::min(x + (e0 + i * de) * y, x + (e0 + (i + 1) * de) * y));
+    }
+    out[(size_t)c] = (float)(lo * (1.0 - 1.0e-6));
+  }
+  return out;
+}
+
 void read_env_knobs(DeviceModel& D) {
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   DeviceModel::Knobs k;
@@ -226,7 +244,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       const int ns = std::min(H.spectrum.num_bins + 1, kMaxSpectrumBins) + 1;
       const int nc = (nv + (1 << 9) - 1) >> 9;  // brackets no coarser than 2^9 table bins
       const long fixed = std::max(shells, 1) * 16 + std::max(nmat, 1) * 8 + ns * 10 + (16 + (long)index_of.size()) * 8 + 2 * kMaxMaterials * 8 +
-                         (long)kSlotWords * kPoolParked * kPoolBlockThreads * 4 + nc * nmat * 2 + nc * 4 + 12 * 16;
+                         (long)kSlotWords * kPoolParked * kPoolBlockThreads * 4 + nc * nmat * 2 + nc * 4 + 12 * 16 +
+                         (((nv + (1 << kWoodShift) - 1) >> kWoodShift) * 4 + 16);
       const long left = 160 * 1024 / 2 - fixed;
       if (left > 0) max_bricks = std::min(max_bricks, std::max(2 * left, 512L));
     }
@@ -401,6 +420,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       r[7] = 0.f;
     }
   D.woodcock = D.put(wood);
+  D.wood_coarse = D.put(coarse_woodcock(H));
   D.mfp = D.put(rec);
   {
     std::vector<float> tot(2 * (size_t)nv * nmat);
@@ -489,6 +509,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.dose_mat = take(2 * kMaxMaterials * 8, 16);
     Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
     take(kSlotWords * kPoolParked * kPoolBlockThreads * 4, 16);
+    Y.wood = take(((nv + (1 << kWoodShift) - 1) >> kWoodShift) * 4, 16);
     Y.sig_mid = Y.sig_w = off;
     D.sig_shift = -1;
     if (!getenv("MCGPU_NO_BRACKETS") && nmat > 0) {
@@ -557,6 +578,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     cold.espc = D.espc; cold.cutoff = D.cutoff; cold.alias = D.alias;
     cold.bricks = D.bricks;
     cold.sig_mid = D.sig_mid; cold.sig_w = D.sig_w;
+    cold.wood_coarse = D.wood_coarse;
     for (int c = 0; c < 16; ++c) cold.brick_palette[c] = D.brick_palette[c];
     // dose tallies (read_input :1868-1893, init_CUDA_device :2636-2657,2694-2720)
     const SimConfig& cfg = H.cfg;
