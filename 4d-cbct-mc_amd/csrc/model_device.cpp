@@ -733,6 +733,10 @@ const void* host_table(mcgpu_ctx& C, const std::string& name, size_t& bytes) {
   if (name == "source_data") DIRECT(H.source);
   if (name == "detector_data") DIRECT(H.detector);
   if (name == "mfp_woodcock") DIRECT(H.mat.woodcock);
+  if (name == "woodcock_coarse") {  // what the FAST kernel stages in LDS (LdsLayout::wood), computed from the table above
+    const std::vector<float> w = coarse_woodcock(H);
+    return cache(w.data(), w.size() * sizeof(float));
+  }
   if (name == "mfp_a") DIRECT(H.mat.a);
   if (name == "mfp_b") DIRECT(H.mat.b);
   if (name == "xco") DIRECT(H.mat.xco);

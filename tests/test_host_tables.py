@@ -155,3 +155,24 @@ def test_s0_bounds_bracket_the_reference_arithmetic(engine, case_dir):
                     assert float(lib.oracle_compton_s(C.byref(T.ct), float(E), cdt, mat, mode)) <= hi, (mat, float(E), cdt)
         print("smallest relative slack of the S0 bounds:", worst)
         assert worst > 2e-5, worst  # the margin of 1e-4 is not eaten by the float arithmetic
+
+
+@pytest.mark.parametrize("name", ["catphan64", "thorax64", "tissue22", "graded_u16"])
+def test_coarse_woodcock_majorant_never_exceeds_the_table(name, case_dir, engine):
+    """The FAST kernel flies with the Woodcock mean free path of a COARSE energy bin (64 table bins, LDS: LdsLayout::wood) instead of
+    interpolating the reference's table (MC-GPU_kernel_v1.3.cu:228).  Delta tracking is exact for any majorant -- i.e. for any mean
+    free path that is NOWHERE larger than the table's: checked here at both ends of every table bin (the table is linear in
+    between), and that it is not wastefully small either (within 12 % of the bin's own minimum above 20 keV)."""
+    with engine.create(case_dir(name), device=-1) as ctx:
+        nv = ctx.geti("num_energy_values")
+        w = ctx.host_table("mfp_woodcock", "<f4").reshape(nv, 2).astype(np.float64)
+        coarse = ctx.host_table("woodcock_coarse", "<f4").astype(np.float64)
+        e0, ide = ctx.getf("e0"), ctx.getf("ide")
+    assert coarse.size == (nv + 63) // 64
+    i = np.arange(nv)
+    lo_end, hi_end = w[:, 0] + (e0 + i / ide) * w[:, 1], w[:, 0] + (e0 + (i + 1) / ide) * w[:, 1]
+    fine_min = np.minimum(lo_end, hi_end)
+    c = coarse[i >> 6]
+    assert np.all(c > 0) and np.all(c <= fine_min * (1.0 - 5e-7)), float((c / fine_min).max())
+    e = e0 + i / ide
+    assert (c / fine_min)[e > 20000.0].min() > 0.88
