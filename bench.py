@@ -532,6 +532,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=512, help="catphan workload: cube edge")
     ap.add_argument("--projections", type=int, default=894)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="host time budget of the cpu_baseline leg (bounded sample of the same workload)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the pipelined-scan measurements after the timed region")
     ap.add_argument("--no-compat", action="store_true", help="skip the COMPAT-personality leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the CIRS / thorax legs (configs 3-5)")
@@ -911,7 +912,7 @@ def main():
                 if not args.no_fdk:
                     out["fdk"] = fdk_leg(cases.pkg, device)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only (the other ranks would idle meanwhile)
-            base, img_cpu, w2_cpu, n_cpu = cpu_baseline(ctx)
+            base, img_cpu, w2_cpu, n_cpu = cpu_baseline(ctx, seconds_budget=args.cpu_seconds)
             out["cpu_baseline"] = base
             # a second ceiling: one scattered 64-bit atomic add per detected photon; rate measured by
             # tools/archive/micro/atomic_rate.hip on MI355X = 2.37e10/s
