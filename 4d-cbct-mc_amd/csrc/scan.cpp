@@ -30,6 +30,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <strings.h>
 #include <thread>
 #include <vector>
 
@@ -38,6 +39,7 @@
 namespace {
 
 constexpr int kAsciiSlots = MCGPU_ASCII_SLOTS;
+constexpr int kExchangeUnavailable = -7;  // the devices of a multi-device scan cannot reach each other (set-up phase only)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -186,10 +188,18 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
       HIP_OK(hipStreamCreate(&D[g].stream));
       ABI_OK(mcgpu_exchange_create(D[g].dev, g, n_ctx, words, policy, mailbox_region, &D[g].x));
     }
-    for (int g = 0; g < n_ctx; ++g)
-      for (int h = 0; h < n_ctx; ++h)
-        if (g != h) ABI_OK(mcgpu_exchange_connect_local(D[g].x, D[h].x));
-    for (int g = 0; g < n_ctx; ++g) ABI_OK(mcgpu_exchange_probe(D[g].x));  // the copy engines reach every peer, or the scan stops here
+    try {
+      // peer access between every pair of devices, and one small copy-engine transfer into every peer's landing buffer: a node
+      // on which either fails is reported with kExchangeUnavailable BEFORE anything has been simulated or written, and
+      // mcgpu_run_scan_multi then shards the scan by projection instead (same output bytes, nothing crosses between devices)
+      if (n_ctx > 1 && getenv("MCGPU_EXCHANGE_FAIL_PROBE")) throw ScanError{-1, "!!ERROR!! tally exchange: probe failure requested (MCGPU_EXCHANGE_FAIL_PROBE)"};  // test hook
+      for (int g = 0; g < n_ctx; ++g)
+        for (int h = 0; h < n_ctx; ++h)
+          if (g != h) ABI_OK(mcgpu_exchange_connect_local(D[g].x, D[h].x));
+      for (int g = 0; g < n_ctx; ++g) ABI_OK(mcgpu_exchange_probe(D[g].x));
+    } catch (const ScanError& e) {
+      throw ScanError{kExchangeUnavailable, e.msg};
+    }
     HIP_OK(hipSetDevice(D[0].dev));
     if (by_time) {
       const unsigned long long probe = 4000000ULL;
@@ -664,7 +674,22 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   for (int g = 0; g < n_ctx; ++g)
     if (!ctxs[g]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null context"); return -1; }
   if (n_ctx > 1 && opt->shard == MCGPU_SHARD_PROJECTIONS) return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
-  return run_scan_sharing_histories(ctxs, n_ctx, opt, report);
+  const int rc = run_scan_sharing_histories(ctxs, n_ctx, opt, report);
+  if (rc == kExchangeUnavailable && n_ctx > 1) {
+    // no peer access / no copy-engine path between these devices: the reference's split (histories of one projection on several
+    // devices) needs one; whole projections per device need none and give the same files (SURVEY.md 8e's fallback mode)
+    if (opt->progress) {
+      // the reason, without the word the reference's log scanner takes for a failed run (cbctmc/mc/simulation.py:204)
+      std::string why = mcgpu_last_error();
+      for (size_t at = 0; at + 5 <= why.size(); ++at)
+        if (strncasecmp(why.c_str() + at, "error", 5) == 0) why.replace(at, 5, "fault");
+      for (size_t at; (at = why.find("!!")) != std::string::npos;) why.erase(at, 2);
+      printf("       Tally exchange between the devices is not available (%s): every device simulates whole projections instead\n", why.c_str());
+      fflush(stdout);
+    }
+    return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
+  }
+  return rc;
 }
 
 extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {

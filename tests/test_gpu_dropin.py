@@ -176,6 +176,24 @@ def test_executable_sharded_by_projection_equals_single_device(engine, tmp_path,
         assert s1.shape == (7, 96, 128) and np.array_equal(s1, s3), m
 
 
+def test_executable_falls_back_to_projection_sharding_without_an_exchange(engine, tmp_path):
+    """A node whose devices cannot reach each other (no peer access, no copy-engine path: here requested through the test hook
+    MCGPU_EXCHANGE_FAIL_PROBE) must not stop a `--gpus N` run: the set-up phase reports it before anything was simulated and the
+    scan is sharded by projection instead -- same files as the single-device run, one line in the log that says so, and the word
+    "error" nowhere (cbctmc/mc/simulation.py:204 greps for it)."""
+    import os
+    a = cases.build_case("catphan64_ct", tmp_path / "one", n_histories=300_000)
+    b = cases.build_case("catphan64_ct", tmp_path / "two", n_histories=300_000)
+    r1 = subprocess.run([str(engine.EXE_PATH), str(a), "--stacks", "--crop", "128"], capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([str(engine.EXE_PATH), str(b), "--devices", "0,0", "--stacks", "--crop", "128"], capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, MCGPU_EXCHANGE_FAIL_PROBE="1"))
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stdout[-2000:] + r2.stdout[-2000:]
+    assert "every device simulates whole projections instead" in r2.stdout
+    assert not re.search("(?i)error", r1.stdout) and not re.search("(?i)error", r2.stdout), r2.stdout[-1500:]
+    for m in ("total", "unscattered", "scattered"):
+        assert np.array_equal(engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / "two" / f"projections_{m}.mha")), m
+
+
 def test_reference_command_line_through_the_mpirun_shim(engine, tmp_path):
     """What `MCSimulation.run_simulation` executes inside the container (cbctmc/mc/simulation.py:187-198): `mpirun --tag-output
     -v -n <gpus> MC-GPU_v1.3.x <input>`, its stdout scanned for progress lines and for the word "error", its projection files
