@@ -119,6 +119,10 @@ struct TrackCold {
   int shell_first[25];                 // index of the first Compton shell of compact material mc in the LDS shell table
   // FAST kernel, scheduling points only (kept out of the launch arguments = out of the SGPR file)
   float objbox_lo[3], objbox_hi[3];    // object box [cm]: outside it every brick is kBrickExterior
+  // ... and so is every brick that lies wholly outside the elliptic cylinder (axis z) ((x - c0)^2 inv0 + (y - c1)^2 inv1 <= 1)
+  // the host fits around everything that is not background: bodies in a CBCT volume are round, and a quarter of their bounding
+  // box is corner air.  The object region of exterior_hop / source_entry is box AND cylinder; inv = {0, 0}: no cylinder.
+  float ell_c[2], ell_inv[2];
   // parked histories per wave64 that trigger a batched service of that kind; service everything well populated when
   // fewer lanes than `flyable_low` can fly; stop for a scheduling point once `swap_batch` more lanes have parked
   int thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch;

@@ -171,23 +171,35 @@ int mcgpu_warp_geometry(mcgpu_ctx* ctx, const float* displacement, int frame, in
     const std::vector<float> coarse = coarse_woodcock(H);  // the FAST kernel's LDS copy of the majorant follows the table
     HIP_TRY(hipMemcpy(D.wood_coarse, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice));
   }
-  D.bricks_mixed = (int)out[14]; D.bricks_exterior = (int)out[15]; D.sub_mixed = (int)out[16];
-  const int had_exterior = D.has_exterior;
-  D.has_exterior = out[15] > 0 ? 1 : 0;
-  if (D.has_exterior) {
-    const int k = D.brick_shift;
-    for (int a = 0; a < 3; ++a) {
-      D.objbox_lo[a] = (float)((int)out[8 + a] << k) * H.voxels.voxel_size[a];
-      D.objbox_hi[a] = (float)std::min(((int)out[11 + a] + 1) << k, H.voxels.n[a]) * H.voxels.voxel_size[a];
-      D.cold_host.objbox_lo[a] = D.objbox_lo[a];
-      D.cold_host.objbox_hi[a] = D.objbox_hi[a];
+  D.sub_mixed = (int)out[16];
+  // The object region (box and, where it pays, elliptic cylinder) and the first-level codes follow from the bricks' classification
+  // exactly as at upload (mark_exterior_region): 64 KB of `brick_first` come down, 16 KB of codes go up.
+  {
+    const int had_exterior = D.has_exterior;
+    std::vector<unsigned short> bf((size_t)D.brick_count);
+    HIP_TRY(hipMemcpy(bf.data(), D.brick_first, bf.size() * 2, hipMemcpyDeviceToHost));
+    std::vector<unsigned char> object((size_t)D.brick_count), exterior;
+    for (int b = 0; b < D.brick_count; ++b) object[(size_t)b] = (bf[(size_t)b] == 0x100 || (int)bf[(size_t)b] != D.background) ? 1 : 0;
+    mark_exterior_region(H, D, object, true, exterior);
+    std::vector<unsigned char> bricks((size_t)D.brick_bytes, 0xFF);
+    D.bricks_mixed = 0;
+    for (int b = 0; b < D.brick_count; ++b) {
+      const int code = exterior[(size_t)b] ? 14 : (bf[(size_t)b] == 0x100 ? 0xF : (int)D.code_of[bf[(size_t)b]]);
+      D.bricks_mixed += (code == 0xF);
+      const int sh = (b & 1) * 4;
+      bricks[(size_t)(b >> 1)] = (unsigned char)((bricks[(size_t)(b >> 1)] & ~(0xF << sh)) | (code << sh));
     }
-    // code 14 means "background outside the object box" (pack_codes_kernel): its palette slot must name the background
-    // even when the BASE geometry had no exterior (its object box spanned the whole brick grid) and the warp made one
-    D.brick_palette[14] = D.background;
-    D.cold_host.brick_palette[14] = D.background;
+    HIP_TRY(hipMemcpy(D.bricks, bricks.data(), bricks.size(), hipMemcpyHostToDevice));
+    for (int a = 0; a < 3; ++a) { D.cold_host.objbox_lo[a] = D.objbox_lo[a]; D.cold_host.objbox_hi[a] = D.objbox_hi[a]; }
+    for (int a = 0; a < 2; ++a) { D.cold_host.ell_c[a] = D.ell_c[a]; D.cold_host.ell_inv[a] = D.ell_inv[a]; }
+    if (D.has_exterior) {
+      // code 14 means "background outside the object region": its palette slot must name the background even when the BASE
+      // geometry had no exterior (its object box spanned the whole brick grid) and the warp made one
+      D.brick_palette[14] = D.background;
+      D.cold_host.brick_palette[14] = D.background;
+    }
+    if (D.has_exterior || had_exterior) HIP_TRY(hipMemcpy(D.cold, &D.cold_host, sizeof D.cold_host, hipMemcpyHostToDevice));
   }
-  if (D.has_exterior || had_exterior) HIP_TRY(hipMemcpy(D.cold, &D.cold_host, sizeof D.cold_host, hipMemcpyHostToDevice));
   ctx->host_voxels_stale = true;
   ctx->table_cache.clear();
   return 0;

@@ -89,6 +89,7 @@ struct DeviceModel {
   int brick_palette[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int has_exterior = 0, bricks_exterior = 0;
   float objbox_lo[3] = {0, 0, 0}, objbox_hi[3] = {0, 0, 0};
+  float ell_c[2] = {0, 0}, ell_inv[2] = {0, 0};  // elliptic cylinder around the object (TrackCold::ell_*); inv 0: none
   int num_spectrum_bins = 0;
   int shell_first[kMaxMaterials] = {0};
   LdsLayout lds;
@@ -178,6 +179,8 @@ struct mcgpu_ctx {
 namespace mcgpu {
 // model_device.cpp
 std::vector<float> coarse_woodcock(const HostModel& H);  // LdsLayout::wood from the host's Woodcock table
+void mark_exterior_region(const HostModel& H, DeviceModel& D, const std::vector<unsigned char>& object, bool have_background,
+                          std::vector<unsigned char>& exterior);  // object box + elliptic cylinder, exterior bricks (upload and device-side warp)
 void read_env_knobs(DeviceModel& D);
 void apply_schedule(DeviceModel& D);
 void upload_model(mcgpu_ctx& C, int device_id);

@@ -22,6 +22,91 @@ std::vector<float> coarse_woodcock(const HostModel& H) {
   return out;
 }
 
+// The object region of a u8 volume and the bricks outside it.  `object[b]` != 0: brick b holds something that is not homogeneous
+// background.  Region = the bounding box of those bricks AND -- bodies in a CBCT volume are round, a quarter of their bounding box
+// is corner air -- an elliptic cylinder (axis z) with the centre and the aspect of that box, scaled until every corner of every
+// object brick is inside; kept only if it puts at least 5 % of the box's bricks outside (else the kernel would pay its quadratic
+// for nothing; MCGPU_NO_ELLIPSE: never).  Sets D.objbox_*, D.ell_*, D.has_exterior, D.bricks_exterior; exterior[b] != 0: brick b lies
+// wholly outside the region.  Shared by the upload of a geometry and by the device-side geometry change (mcgpu_warp_geometry).
+void mark_exterior_region(const HostModel& H, DeviceModel& D, const std::vector<unsigned char>& object, bool have_background,
+                          std::vector<unsigned char>& exterior) {
+  const int k = D.brick_shift, nvx[3] = {H.voxels.n[0], H.voxels.n[1], H.voxels.n[2]};
+  exterior.assign((size_t)D.brick_count, 0);
+  D.has_exterior = 0;
+  D.bricks_exterior = 0;
+  D.ell_inv[0] = D.ell_inv[1] = 0.f;
+  int lo[3] = {D.brick_n[0], D.brick_n[1], D.brick_n[2]}, hi[3] = {-1, -1, -1};
+  auto coords = [&](int b, int c3[3]) { c3[0] = b % D.brick_n[0]; c3[1] = (b / D.brick_n[0]) % D.brick_n[1]; c3[2] = b / (D.brick_n[0] * D.brick_n[1]); };
+  for (int b = 0; b < D.brick_count; ++b) {
+    if (!object[(size_t)b]) continue;
+    int c3[3];
+    coords(b, c3);
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c3[a]); hi[a] = std::max(hi[a], c3[a]); }
+  }
+  if (!have_background || hi[0] < 0 || D.knobs.no_exterior) return;
+  const float bs = (float)(1 << k);
+  auto brick_rect = [&](const int c3[3], float r[4]) {
+    r[0] = (float)c3[0] * bs * H.voxels.voxel_size[0]; r[1] = std::min((float)(c3[0] + 1) * bs, (float)nvx[0]) * H.voxels.voxel_size[0];
+    r[2] = (float)c3[1] * bs * H.voxels.voxel_size[1]; r[3] = std::min((float)(c3[1] + 1) * bs, (float)nvx[1]) * H.voxels.voxel_size[1];
+  };
+  float box_lo[3], box_hi[3];
+  for (int a = 0; a < 3; ++a) {
+    box_lo[a] = (float)(lo[a] << k) * H.voxels.voxel_size[a];
+    box_hi[a] = (float)std::min((hi[a] + 1) << k, nvx[a]) * H.voxels.voxel_size[a];
+  }
+  const float ecx = 0.5f * (box_lo[0] + box_hi[0]), ecy = 0.5f * (box_lo[1] + box_hi[1]);
+  const float ea = 0.5f * (box_hi[0] - box_lo[0]), eb = 0.5f * (box_hi[1] - box_lo[1]);
+  float inv[2] = {0.f, 0.f};
+  if (ea > 0.f && eb > 0.f && !getenv("MCGPU_NO_ELLIPSE")) {
+    double s2 = 0.0;
+    for (int b = 0; b < D.brick_count; ++b) {
+      if (!object[(size_t)b]) continue;
+      int c3[3];
+      float r[4];
+      coords(b, c3);
+      brick_rect(c3, r);
+      for (int c = 0; c < 4; ++c) {
+        const double dx = ((c & 1) ? r[1] : r[0]) - ecx, dy = ((c & 2) ? r[3] : r[2]) - ecy;
+        s2 = std::max(s2, dx * dx / ((double)ea * ea) + dy * dy / ((double)eb * eb));
+      }
+    }
+    s2 *= 1.0 + 1.0e-4;
+    inv[0] = (float)(1.0 / (s2 * (double)ea * ea));
+    inv[1] = (float)(1.0 / (s2 * (double)eb * eb));
+  }
+  auto outside_cylinder = [&](const int c3[3]) {  // wholly outside: the point of the brick's rectangle nearest to the axis is
+    float r[4];
+    brick_rect(c3, r);
+    const float px = std::min(std::max(ecx, r[0]), r[1]) - ecx, py = std::min(std::max(ecy, r[2]), r[3]) - ecy;
+    return px * px * inv[0] + py * py * inv[1] > 1.001f;
+  };
+  long in_box = 0, cut = 0;
+  if (inv[0] > 0.f) {
+    for (int b = 0; b < D.brick_count; ++b) {
+      int c3[3];
+      coords(b, c3);
+      if (c3[0] < lo[0] || c3[0] > hi[0] || c3[1] < lo[1] || c3[1] > hi[1] || c3[2] < lo[2] || c3[2] > hi[2]) continue;
+      ++in_box;
+      cut += outside_cylinder(c3) ? 1 : 0;
+    }
+    if (cut * 20 < in_box) inv[0] = inv[1] = 0.f;  // the cylinder would hardly trim the box: not worth its arithmetic
+  }
+  long outside = 0;
+  for (int b = 0; b < D.brick_count; ++b) {
+    int c3[3];
+    coords(b, c3);
+    bool out = c3[0] < lo[0] || c3[0] > hi[0] || c3[1] < lo[1] || c3[1] > hi[1] || c3[2] < lo[2] || c3[2] > hi[2];
+    if (!out && inv[0] > 0.f) out = outside_cylinder(c3);
+    if (out) { exterior[(size_t)b] = 1; ++outside; }
+  }
+  if (outside == 0) return;
+  D.has_exterior = 1;
+  D.bricks_exterior = (int)outside;
+  for (int a = 0; a < 3; ++a) { D.objbox_lo[a] = box_lo[a]; D.objbox_hi[a] = box_hi[a]; }
+  D.ell_c[0] = ecx; D.ell_c[1] = ecy;
+  D.ell_inv[0] = inv[0]; D.ell_inv[1] = inv[1];
+}
+
 void read_env_knobs(DeviceModel& D) {
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   DeviceModel::Knobs k;
@@ -290,38 +375,17 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     D.brick_palette[14] = D.brick_palette[15] = 0;
     for (int i = 0; i < 256; ++i) D.code_of[i] = (unsigned char)code_of[i];
     D.background = order[0];
-    // Exterior: the object box is the bounding box (in bricks) of every brick that is not homogeneous background
-    // (background = the most frequent homogeneous entry).  Bricks outside it are all background: the FAST kernel crosses
-    // that region with one exact free-path sample instead of delta-tracking through it (track_pool.inc: exterior_hop).
-    D.has_exterior = 0;
+    // Exterior (mark_exterior_region): outside the object region every brick is homogeneous background, and the FAST kernel crosses
+    // it with one exact free-path sample instead of delta-tracking through it (track_pool.inc: exterior_hop).
     {
       const int bg = order[0];
-      int lo[3] = {D.brick_n[0], D.brick_n[1], D.brick_n[2]}, hi[3] = {-1, -1, -1};
-      for (int bz = 0; bz < D.brick_n[2]; ++bz)
-        for (int by = 0; by < D.brick_n[1]; ++by)
-          for (int bx = 0; bx < D.brick_n[0]; ++bx) {
-            const int b = (bz * D.brick_n[1] + by) * D.brick_n[0] + bx;
-            if (!mixed[b] && first[b] == bg) continue;
-            const int c3[3] = {bx, by, bz};
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c3[a]); hi[a] = std::max(hi[a], c3[a]); }
-          }
-      if (homogeneous[bg] > 0 && hi[0] >= 0 && !D.knobs.no_exterior) {
-        long outside = 0;
-        for (int b = 0; b < D.brick_count; ++b) {
-          const int bx = b % D.brick_n[0], by = (b / D.brick_n[0]) % D.brick_n[1], bz = b / (D.brick_n[0] * D.brick_n[1]);
-          const bool out = bx < lo[0] || bx > hi[0] || by < lo[1] || by > hi[1] || bz < lo[2] || bz > hi[2];
-          if (out) { first[b] = -2; ++outside; }  // marks EXTERIOR for the encoder below
-        }
-        if (outside > 0) {
-          D.has_exterior = 1;
-          D.brick_palette[14] = bg;
-          const int nvx[3] = {nx, ny, nz};
-          for (int a = 0; a < 3; ++a) {
-            D.objbox_lo[a] = (float)(lo[a] << k) * H.voxels.voxel_size[a];
-            D.objbox_hi[a] = (float)std::min((hi[a] + 1) << k, nvx[a]) * H.voxels.voxel_size[a];
-          }
-        }
-      }
+      std::vector<unsigned char> object((size_t)D.brick_count, 0);
+      for (int b = 0; b < D.brick_count; ++b) object[(size_t)b] = (mixed[b] || first[b] != bg) ? 1 : 0;
+      std::vector<unsigned char> exterior;
+      mark_exterior_region(H, D, object, homogeneous[bg] > 0, exterior);
+      for (int b = 0; b < D.brick_count; ++b)
+        if (exterior[(size_t)b]) first[b] = -2;  // marks EXTERIOR for the encoder below
+      if (D.has_exterior) D.brick_palette[14] = bg;
     }
     D.brick_bytes = (D.brick_count + 1) / 2;
     std::vector<unsigned char> bricks(D.brick_bytes, 0xFF);
@@ -599,6 +663,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
     for (int m = 0; m < kMaxMaterials; ++m) cold.shell_first[m] = D.shell_first[m];
     for (int k = 0; k < 3; ++k) { cold.objbox_lo[k] = D.objbox_lo[k]; cold.objbox_hi[k] = D.objbox_hi[k]; }
+    for (int k = 0; k < 2; ++k) { cold.ell_c[k] = D.ell_c[k]; cold.ell_inv[k] = D.ell_inv[k]; }
     cold.thresh_compton = cold.thresh_rayleigh = cold.thresh_new = cold.flyable_low = cold.swap_batch = cold.trade_slots = -1;  // apply_schedule
     {
       // azimuthal aperture of the beam (the same for every projection: the pose rotates the beam frame, MC-GPU_v1.3.cu:3280-3434)
