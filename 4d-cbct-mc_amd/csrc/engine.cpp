@@ -88,6 +88,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "brick_count") *value = ctx->dev.brick_count;
   else if (k == "bricks_mixed") *value = ctx->dev.bricks_mixed;
   else if (k == "bricks_exterior") *value = ctx->dev.bricks_exterior;
+  else if (k == "exterior_cylinder") *value = ctx->dev.ell_inv[0] > 0.f ? 1 : 0;  // object region = box AND elliptic cylinder (mark_exterior_region)
   else if (k == "sub_bricks") *value = (long long)ctx->dev.sub_n[0] * ctx->dev.sub_n[1] * ctx->dev.sub_n[2];
   else if (k == "sub_bricks_mixed") *value = ctx->dev.sub_mixed;
   else if (k == "tile_records") *value = ctx->dev.tile_rec ? 1 : 0;

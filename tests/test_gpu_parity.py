@@ -338,6 +338,36 @@ def test_fast_exterior_hop_is_statistically_equivalent_to_delta_tracking(gpu_eng
     assert np.mean(np.abs(z[mask]) > 3.0) < 0.01 and np.abs(z[mask]).max() < 6.0 and abs(z[mask].mean()) < 0.1
 
 
+def test_fast_object_region_with_and_without_the_elliptic_cylinder(gpu_engine, case_dir, monkeypatch):
+    """The object region of the exterior hop is the bounding box of everything that is not background AND, where it removes at least
+    5 % of the box's bricks, an elliptic cylinder around it (model_device.cpp: mark_exterior_region; MCGPU_NO_ELLIPSE: box alone).
+    Both regions hold the whole object, so the two runs are independent estimates of the same images; the cylinder must be in use
+    on a round phantom and must mark more bricks exterior than the box."""
+    n = 20_000_000
+    res = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MCGPU_NO_ELLIPSE", "1")
+        for case in ("catphan64", "thorax64"):
+            with gpu_engine.create(case_dir(case), device=0) as ctx:
+                res[(case, off)] = (ctx.geti("exterior_cylinder"), ctx.geti("bricks_exterior"), ctx.run_projection(0, n, mode="fast", seed=11 + off)[0])
+    assert any(res[(case, False)][0] == 1 for case in ("catphan64", "thorax64"))
+    for case in ("catphan64", "thorax64"):
+        (cyl, ext, img), (cyl0, ext0, img0) = res[(case, False)], res[(case, True)]
+        assert cyl0 == 0 and (ext > ext0 if cyl else ext == ext0), (case, cyl, ext, ext0)
+        # A sum S of tally weights w (unit 0.01 eV, w <= 1.5e7) has variance sum(w^2) <= 1.5e7 S: a bound on the sigma of every
+        # class energy and block, somewhat above the true one (the mean photon carries ~6e6 units)
+        for k in range(4):
+            a, b = img[k].sum(dtype=np.float64), img0[k].sum(dtype=np.float64)
+            if min(a, b) < 1e10:
+                continue
+            assert abs(a / b - 1.0) < 5.0 * np.sqrt(2.0 * 1.5e7 / min(a, b)), (case, k, a / b - 1.0)
+        g, c = parity.blocks(img)[0].astype(np.float64), parity.blocks(img0)[0].astype(np.float64)
+        m = (g > 1e10) & (c > 1e10)  # blocks of the primary image with well over a thousand photons
+        z = (g[m] - c[m]) / np.sqrt((g[m] + c[m]) * 1.5e7)
+        assert m.sum() > 20 and abs(z.mean()) < 5.0 / np.sqrt(m.sum()) and np.abs(z).max() < 6.0, (case, int(m.sum()), z.mean(), np.abs(z).max())
+
+
 @pytest.mark.parametrize("case,projection,fixture", [("catphan64", 0, "stat_catphan64.npz"), ("slab_angles", 1, "stat_slab_angles_p1.npz")])
 def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, case, projection, fixture):
     """FAST vs tests/golden/stat_*.npz: 16 independent runs of the CPU oracle in its
