@@ -66,6 +66,8 @@ constexpr int kPoolWavesPerSimd = 2 * kPoolBlockThreads / 64 / 4;  // two workgr
 constexpr int kMaxBricks = 32768;         // brick grid budget: 4 bits each -> 16 KiB of LDS
 constexpr int kNumCounters = 64, kCounterStride = 32;  // FAST: history-id dispensers (u64 each, 256 B apart)
 constexpr int kWoodShift = 6;             // FAST: coarse Woodcock bins of 64 table bins (320 eV): 376 floats of LDS
+constexpr int kPoolKinds = 4;             // FAST, workgroup-level pool: kinds of work a parked history can wait for
+constexpr int kPoolQueueBytes = 64 + kPoolKinds * kPoolBlockThreads * 2;  // control block + rings (LdsLayout::queues)
 constexpr int kSlotWords = 12;            // dwords of a parked history in its lane-private LDS slot (FAST kernel)
 constexpr int kS0Bins = 1024;            // COMPAT: energy bins of the S0 bounds (TrackCold::s0_bounds)
 constexpr int kNumStats = 32;             // scheduler counters of the diagnostic build
@@ -90,6 +92,9 @@ struct LdsLayout {
   // a history may use the coarse one (a few % more virtual interactions at low energies) and the kernel needs no table fetch from
   // memory when a Compton event or a new photon changes the energy: one dependent round trip fewer per service batch.
   int wood;                  // float[ceil(num_values / 2^kWoodShift)]
+  // FAST kernel, workgroup-level pool (track_pool.inc: track_wg_kernel): u32 control block {tail[4], head[4], count[4], panic},
+  // then one ring of kPoolBlockThreads u16 slot ids per kind of work {flight, Compton, Rayleigh, tally + source}
+  int queues;
   int total;                 // bytes
 };
 
@@ -148,6 +153,7 @@ struct TrackArgs {
   const unsigned char* sub;  // FAST: second level, dense over the 4^3-voxel tiles (null: none): 4-bit codes, or TileRecord[] (sub_kind 2)
   int sub_nx, sub_nxy;
   int sub_kind;              // host-side dispatch only: 0 none, 1 four-bit codes, 2 tile records
+  int sched_kind;            // host-side dispatch only: FAST scheduler, 0 = per-wave pools, 1 = workgroup-level pool
   int rec_nx, rec_nxy;       // tile records: cubes of 2x2x2 tiles per row / per slab (tile_record_index)
   int nx, ny, nz, nxy;
   float inv_vs[3];

@@ -92,6 +92,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "sub_bricks") *value = (long long)ctx->dev.sub_n[0] * ctx->dev.sub_n[1] * ctx->dev.sub_n[2];
   else if (k == "sub_bricks_mixed") *value = ctx->dev.sub_mixed;
   else if (k == "tile_records") *value = ctx->dev.tile_rec ? 1 : 0;
+  else if (k == "fast_scheduler") *value = ctx->dev.knobs.fast_sched;  // 0: per-wave pools, 1: workgroup-level pool (MCGPU_FAST_SCHED at upload)
   else if (k == "tiles_in_mixed_bricks") *value = ctx->dev.tiles_in_mixed_bricks;
   else if (k == "blocks_per_cu") *value = ctx->dev.resident_fast;
   else if (k == "lds_bytes_fast") *value = ctx->dev.lds.total;
@@ -233,6 +234,7 @@ int mcgpu_set_fast_schedule(mcgpu_ctx* ctx, int thresh_compton, int thresh_rayle
           -2, "!!ERROR!! mcgpu_set_fast_schedule: thresholds are lane counts in 1..64");
   const int v[5] = {thresh_compton, thresh_rayleigh, thresh_new, flyable_low, swap_batch};
   for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = v[k];
+  ctx->dev.sched_set = true;
   apply_schedule(ctx->dev);
   return 0;
   ABI_END
@@ -241,7 +243,9 @@ int mcgpu_set_fast_schedule(mcgpu_ctx* ctx, int thresh_compton, int thresh_rayle
 int mcgpu_reload_env_knobs(mcgpu_ctx* ctx) {
   ABI_BEGIN
   require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_reload_env_knobs: no device context");
+  const int sched_kind = ctx->dev.knobs.fast_sched;  // fixed when the model was uploaded (it shapes the LDS image)
   read_env_knobs(ctx->dev);
+  ctx->dev.knobs.fast_sched = sched_kind;
   ctx->dev.resident_fast = 0;  // MCGPU_BLOCKS_PER_CU may have changed: asked again at the next launch
   apply_schedule(ctx->dev);
   return 0;

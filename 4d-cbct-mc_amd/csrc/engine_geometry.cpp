@@ -96,6 +96,7 @@ int mcgpu_set_geometry_arrays(mcgpu_ctx* ctx, const int n[3], const float spacin
       throw;
     }
     for (int k = 0; k < 5; ++k) ctx->dev.sched[k] = old.sched[k];  // the tuned FAST schedule survives a geometry change
+    ctx->dev.sched_set = old.sched_set;
     apply_schedule(ctx->dev);
     old.release();  // NB: the dose tallies belong to a geometry and restart from zero with the new one
   }

@@ -111,6 +111,7 @@ struct DeviceModel {
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
   int sched[5] = {32, 8, 36, 12, 40};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
+  bool sched_set = false;              // mcgpu_set_fast_schedule has been called (else the scheduler's own defaults apply)
   // Tuning knobs of the environment.  Read when the device model is built and again only by
   // mcgpu_reload_env_knobs: the launch path itself never looks at the environment and never synchronises.
   struct Knobs {
@@ -122,6 +123,7 @@ struct DeviceModel {
     int sched_override[5] = {-1, -1, -1, -1, -1};    // MCGPU_THRESH_{COMPTON,RAYLEIGH,NEW}, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH (-1: sched[])
     int slot_trade = 3, hold_q = 6;                  // MCGPU_SLOT_TRADE, MCGPU_HOLD_Q
     bool no_exterior = false;                        // MCGPU_NO_EXTERIOR (also read by the geometry builders)
+    int fast_sched = 0;                              // MCGPU_FAST_SCHED: 0 per-wave pools, 1 workgroup-level pool (fixes the LDS layout: read at upload)
   } knobs;
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder
   float *xco = nullptr, *pco = nullptr, *aco = nullptr, *bco = nullptr;

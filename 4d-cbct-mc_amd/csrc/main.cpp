@@ -12,6 +12,9 @@
 //   --shard histories|projections   with several devices: share every projection's histories (default: the reference's split,
 //                        tallies summed through the exchange) or give every device whole projections (no traffic between the
 //                        devices at all: the fallback for nodes without working peer access; same output bytes)
+//   --reduce exchange|rccl   with several devices sharing histories: sum the per-device tallies through the tally exchange (default; falls
+//                        back to RCCL, then to projection sharding, where the devices cannot reach each other) or with ONE
+//                        ncclReduce(uint64, sum) per projection (the reference's MPI_Reduce, MC-GPU_v1.3.cu:1019; RCCL is opened with dlopen)
 //   --no-output          skip the ASCII projection files (timing runs, or stacks only)
 //   --stacks             also write projections_{total,unscattered,scattered}.mha next to the projection files
 //                        (what cbctmc/mc/simulation.py:235-277 builds from the ASCII files afterwards)
@@ -37,7 +40,7 @@ int main(int argc, char** argv) {
     printf("\n\n   !!read_input ERROR!! Input file name not given as an execution parameter!! Try again...\n\n");
     return 255;
   }
-  int mode = MCGPU_MODE_FAST, ngpu = 1, shard = MCGPU_SHARD_HISTORIES;
+  int mode = MCGPU_MODE_FAST, ngpu = 1, shard = MCGPU_SHARD_HISTORIES, reduce = MCGPU_REDUCE_AUTO;
   bool write_out = true, stacks = false;
   int crop = -1;
   const char* air = nullptr;
@@ -55,6 +58,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = !strcmp(argv[++i], "compat") ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--shard") && i + 1 < argc) shard = !strcmp(argv[++i], "projections") ? MCGPU_SHARD_PROJECTIONS : MCGPU_SHARD_HISTORIES;
+    else if (!strcmp(argv[i], "--reduce") && i + 1 < argc) reduce = !strcmp(argv[++i], "rccl") ? MCGPU_REDUCE_RCCL : MCGPU_REDUCE_AUTO;
     else if (!strcmp(argv[i], "--no-output")) write_out = false;
   }
   if (!device_list.empty()) ngpu = (int)device_list.size();
@@ -96,6 +100,7 @@ int main(int argc, char** argv) {
   so.mode = mode;
   so.progress = 1;
   so.shard = shard;
+  so.reduce = reduce;
   so.crop_nx = (crop > 0 && crop < det_nx) ? crop : (int)det_nx;
   so.write_ascii = write_out ? 1 : 0;
   so.write_stacks = stacks ? 1 : 0;

@@ -123,6 +123,7 @@ void read_env_knobs(DeviceModel& D) {
   k.slot_trade = env_int("MCGPU_SLOT_TRADE", 3);
   k.hold_q = env_int("MCGPU_HOLD_Q", 6) & 15;
   k.no_exterior = getenv("MCGPU_NO_EXTERIOR") != nullptr;
+  k.fast_sched = env_int("MCGPU_FAST_SCHED", D.knobs.fast_sched) != 0 ? 1 : 0;
   D.knobs = k;
 }
 
@@ -133,7 +134,10 @@ void apply_schedule(DeviceModel& D) {
   if (!D.cold) return;
   TrackCold& ch = D.cold_host;
   int want[5];
-  for (int i = 0; i < 5; ++i) want[i] = D.knobs.sched_override[i] >= 0 ? D.knobs.sched_override[i] : D.sched[i];
+  // the workgroup-level pool fills its batches from the whole workgroup: its thresholds are "lanes a batch must fill"
+  static const int kWgSched[5] = {56, 56, 56, 40, 40};
+  for (int i = 0; i < 5; ++i)
+    want[i] = D.knobs.sched_override[i] >= 0 ? D.knobs.sched_override[i] : ((D.knobs.fast_sched == 1 && !D.sched_set) ? kWgSched[i] : D.sched[i]);
   want[3] = std::max(1, want[3]);
   want[4] = std::max(1, want[4]);
   // bit 0: slots traded before flight, bit 1: before the Compton and tally/source services; bits 8-11: hold_q (sixteenths
@@ -329,7 +333,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       const int ns = std::min(H.spectrum.num_bins + 1, kMaxSpectrumBins) + 1;
       const int nc = (nv + (1 << 9) - 1) >> 9;  // brackets no coarser than 2^9 table bins
       const long fixed = std::max(shells, 1) * 16 + std::max(nmat, 1) * 8 + ns * 10 + (16 + (long)index_of.size()) * 8 + 2 * kMaxMaterials * 8 +
-                         (long)kSlotWords * kPoolParked * kPoolBlockThreads * 4 + nc * nmat * 2 + nc * 4 + 12 * 16 +
+                         (long)kSlotWords * kPoolParked * kPoolBlockThreads * 4 + (D.knobs.fast_sched == 1 ? kPoolQueueBytes : 0) + nc * nmat * 2 + nc * 4 +
+                         12 * 16 +
                          (((nv + (1 << kWoodShift) - 1) >> kWoodShift) * 4 + 16);
       const long left = 160 * 1024 / 2 - fixed;
       if (left > 0) max_bricks = std::min(max_bricks, std::max(2 * left, 512L));
@@ -573,6 +578,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.dose_mat = take(2 * kMaxMaterials * 8, 16);
     Y.slots = take(0, 16);  // the COMPAT kernel's image ends here
     take(kSlotWords * kPoolParked * kPoolBlockThreads * 4, 16);
+    Y.queues = D.knobs.fast_sched == 1 ? take(kPoolQueueBytes, 16) : 0;
     Y.wood = take(((nv + (1 << kWoodShift) - 1) >> kWoodShift) * 4, 16);
     Y.sig_mid = Y.sig_w = off;
     D.sig_shift = -1;
@@ -727,6 +733,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.stream_key = (unsigned)p;
   A.dose_flags = D.dose_flags;
 
+  A.sched_kind = D.knobs.fast_sched;
   A.has_exterior = (D.vol_kind == kVolU8 && D.has_exterior) ? D.knobs.exterior_mode : 0;  // bit 0: hop during flight, bit 1: hop at the source
   // batching thresholds of the COMPAT kernel (lanes of a wave64 holding such a history in their registers or their parking slot)
   // The Compton batch of the COMPAT kernel walks every electron shell of the material several times in the reference's own

@@ -40,6 +40,7 @@ namespace {
 
 constexpr int kAsciiSlots = MCGPU_ASCII_SLOTS;
 constexpr int kExchangeUnavailable = -7;  // the devices of a multi-device scan cannot reach each other (set-up phase only)
+constexpr int kRcclUnavailable = -8;      // the RCCL route cannot be set up on these devices (set-up phase only)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -69,6 +70,12 @@ struct DeviceLane {  // per device
   hipEvent_t done[2] = {nullptr, nullptr};     // planes of pinned buffer b are on the host (system-scope release; copy stream)
   bool done_valid[2] = {false, false};
   unsigned long long lo = 0, hi = 0;           // shard of the units of every projection
+  // RCCL route (reduce_rccl.cpp): the collective runs on a stream of its own, beside the next projection's kernel
+  hipStream_t reduce = nullptr;
+  void* tally[2] = {nullptr, nullptr};         // this device's tally of the projection with that parity
+  hipEvent_t tracked[2] = {nullptr, nullptr};  // the tracking kernel of that projection has run (tracking stream)
+  hipEvent_t reduced[2] = {nullptr, nullptr};  // the collective over that tally has run here (reduce stream)
+  bool reduced_valid[2] = {false, false};
 };
 
 }  // namespace
@@ -77,9 +84,29 @@ extern "C" void mcgpu_set_last_error_(const char* message);  // engine.cpp (not 
 
 namespace {
 
+// An input history count below 95000 is a time budget in seconds per projection (MC-GPU_v1.3.cu:650-655, :689-809: the reference
+// runs a speed test and converts).  Two throw-away launches on `ctx`'s device; returns its rate in x-rays per second.
+double calibrate_rate(mcgpu_ctx* ctx, int dev, int projection, int mode, long long seed, long long hpt, size_t words, void** probe_image, hipStream_t stream) {
+  const unsigned long long probe = 4000000ULL;
+  const unsigned long long probe_units = mode == MCGPU_MODE_COMPAT ? (probe + (unsigned long long)hpt - 1) / (unsigned long long)hpt : probe;
+  float ms = 0.f;
+  HIP_OK(hipSetDevice(dev));
+  if (!*probe_image) HIP_OK(hipMalloc(probe_image, words * 8));
+  HIP_OK(hipMemsetAsync(*probe_image, 0, words * 8, stream));
+  for (int rep = 0; rep < 2; ++rep) {  // the first launch pays one-off costs
+    ABI_OK(mcgpu_launch_projection(ctx, projection, mode, (int)seed, 0, probe_units, (int)hpt, *probe_image, stream));
+    ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
+  }
+  ABI_OK(mcgpu_dose_clear(ctx));
+  return (double)probe / (ms > 0.f ? ms * 1e-3 : 1e-3);
+}
+
 // One scan over n_ctx devices that share every projection's histories (n_ctx = 1: the plain single-device pipeline).
-int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {
+// `use_rccl`: the per-device tallies of a projection are summed by one ncclReduce to the projection's owner (reduce_rccl.cpp) instead
+// of through the tally exchange.
+int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report, bool use_rccl = false) {
   std::vector<DeviceLane> D((size_t)n_ctx);
+  mcgpu_rccl* rccl = nullptr;
   float* planes_host[2] = {nullptr, nullptr};
   uint64_t* image_host[2] = {nullptr, nullptr};
   void* probe_image = nullptr;  // tally of the throw-away launches (time calibration, preset choice)
@@ -181,14 +208,31 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     const bool single = (n_ctx == 1);
     int policy = MCGPU_EXCHANGE_LOCAL | MCGPU_EXCHANGE_ROTATE;
     if (const char* v = getenv("MCGPU_EXCHANGE_POLICY")) policy = MCGPU_EXCHANGE_LOCAL | (atoi(v) ? MCGPU_EXCHANGE_ROTATE : 0);
-    mailboxes.assign(mcgpu_exchange_shared_bytes(n_ctx), 0);
+    mailboxes.assign(mcgpu_exchange_shared_bytes(n_ctx) * (size_t)(use_rccl ? n_ctx : 1), 0);
     void* const mailbox_region = mailboxes.data();
+    const bool rotate_owner = (policy & MCGPU_EXCHANGE_ROTATE) != 0;
+    // owner of projection j of this scan: the device that holds the summed tally, finalizes and downloads it
+    auto owner_of = [&](int j) { return use_rccl ? (rotate_owner ? j % n_ctx : 0) : mcgpu_exchange_owner(D[0].x, j); };
     for (int g = 0; g < n_ctx; ++g) {
       HIP_OK(hipSetDevice(D[g].dev));
       HIP_OK(hipStreamCreate(&D[g].stream));
-      ABI_OK(mcgpu_exchange_create(D[g].dev, g, n_ctx, words, policy, mailbox_region, &D[g].x));
+      if (use_rccl) {
+        // every device keeps its double-buffered tally in an exchange end of its own (a world of one: begin / submit / collect stay local)
+        ABI_OK(mcgpu_exchange_create(D[g].dev, 0, 1, words, MCGPU_EXCHANGE_LOCAL, mailboxes.data() + (size_t)g * mcgpu_exchange_shared_bytes(n_ctx), &D[g].x));
+        HIP_OK(hipStreamCreateWithFlags(&D[g].reduce, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+          HIP_OK(hipEventCreateWithFlags(&D[g].tracked[b], hipEventDisableTiming));
+          HIP_OK(hipEventCreateWithFlags(&D[g].reduced[b], hipEventDisableTiming));
+        }
+      } else {
+        ABI_OK(mcgpu_exchange_create(D[g].dev, g, n_ctx, words, policy, mailbox_region, &D[g].x));
+      }
     }
-    try {
+    if (use_rccl) {
+      std::vector<int> devs((size_t)n_ctx);
+      for (int g = 0; g < n_ctx; ++g) devs[(size_t)g] = D[g].dev;
+      if (mcgpu_rccl_create(devs.data(), n_ctx, &rccl) != 0) throw ScanError{kRcclUnavailable, mcgpu_last_error()};
+    } else try {
       // peer access between every pair of devices, and one small copy-engine transfer into every peer's landing buffer: a node
       // on which either fails is reported with kExchangeUnavailable BEFORE anything has been simulated or written, and
       // mcgpu_run_scan_multi then shards the scan by projection instead (same output bytes, nothing crosses between devices)
@@ -202,17 +246,7 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     }
     HIP_OK(hipSetDevice(D[0].dev));
     if (by_time) {
-      const unsigned long long probe = 4000000ULL;
-      const unsigned long long probe_units = mode == MCGPU_MODE_COMPAT ? (probe + (unsigned long long)hpt - 1) / (unsigned long long)hpt : probe;
-      float ms = 0.f;
-      if (!probe_image) HIP_OK(hipMalloc(&probe_image, words * 8));
-      HIP_OK(hipMemsetAsync(probe_image, 0, words * 8, D[0].stream));
-      for (int rep = 0; rep < 2; ++rep) {  // the first launch pays one-off costs
-        ABI_OK(mcgpu_launch_projection(ctx, first, mode, (int)seed, 0, probe_units, (int)hpt, probe_image, D[0].stream));
-        ABI_OK(mcgpu_last_kernel_ms(ctx, &ms));
-      }
-      ABI_OK(mcgpu_dose_clear(ctx));
-      const double rate = (double)probe / (ms > 0.f ? ms * 1e-3 : 1e-3) * n_ctx;
+      const double rate = calibrate_rate(ctx, D[0].dev, first, mode, seed, hpt, words, &probe_image, D[0].stream) * n_ctx;
       H = (unsigned long long)(rate * (double)hist_in);
       if (H < 100000ULL) H = 100000ULL;
       total = H;
@@ -226,7 +260,9 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     // FAST batching thresholds: a few presets timed with throw-away launches on the first simulated projection (the best
     // one differs between geometries by 5-7 %; the tallies do not depend on the choice).  Skipped for short scans and when
     // the environment pins the knobs.
-    if (mode == MCGPU_MODE_FAST && total >= 20000000ULL && !getenv("MCGPU_THRESH_COMPTON") && !getenv("MCGPU_THRESH_NEW") &&
+    long long fast_scheduler = 0;  // the presets are per-wave pool thresholds; the workgroup-level pool keeps its own defaults
+    ABI_OK(mcgpu_config_i64(ctx, "fast_scheduler", &fast_scheduler));
+    if (mode == MCGPU_MODE_FAST && fast_scheduler == 0 && total >= 20000000ULL && !getenv("MCGPU_THRESH_COMPTON") && !getenv("MCGPU_THRESH_NEW") &&
         !getenv("MCGPU_SWAP_BATCH") && !getenv("MCGPU_NO_AUTOTUNE")) {
       static const int presets[3][5] = {{32, 8, 36, 12, 40}, {32, 4, 40, 8, 32}, {24, 8, 36, 12, 24}};
       const unsigned long long probe = 6000000ULL;
@@ -320,7 +356,7 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
           sh.cv.wait(lk, [&] { return sh.queued > i || sh.abort; });
           if (sh.abort) return;
         }
-        const int b = i & 1, p = first + sim[i], o = mcgpu_exchange_owner(D[0].x, i);
+        const int b = i & 1, p = first + sim[i], o = owner_of(i);
         if (hipSetDevice(D[o].dev) != hipSuccess || hipEventSynchronize(D[o].done[b]) != hipSuccess) {
           std::lock_guard<std::mutex> lk(sh.mu);
           sh.error = "!!HIP ERROR!! waiting for projection results";
@@ -376,7 +412,7 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     }
     // sum + finalize of projection j on its owner's stream, then hand it to the writer
     auto enqueue_reduce = [&](int j) {
-      const int b = j & 1, o = mcgpu_exchange_owner(D[0].x, j);
+      const int b = j & 1, o = owner_of(j);
       {  // pinned buffer b is free once projection j-2 has been written.  Formatter slot j % n_ascii was last used by
          // projection j - n_ascii: that one must have been HANDED to its worker (the writer sets ascii_busy when it has
          // written the projection's stacks, together with `written`) and the worker must be done.  With one slot the
@@ -387,10 +423,31 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
         sh.cv.wait(lk, [&] { return (sh.written >= handed && !sh.ascii_busy[j % n_ascii]) || sh.abort; });
         if (sh.abort) throw ScanError{-3, sh.error};
       }
+      if (use_rccl) {
+        // one ncclReduce(uint64, sum, root = owner) over the devices' tallies of projection j (the reference's MPI_Reduce,
+        // MC-GPU_v1.3.cu:1019), on the reduce streams: behind kernel j of each device, beside its kernel j + 1
+        std::vector<void*> bufs((size_t)n_ctx), streams((size_t)n_ctx);
+        for (int g = 0; g < n_ctx; ++g) {
+          HIP_OK(hipSetDevice(D[g].dev));
+          HIP_OK(hipStreamWaitEvent(D[g].reduce, D[g].tracked[b], 0));
+          bufs[(size_t)g] = D[g].tally[b];
+          streams[(size_t)g] = (void*)D[g].reduce;
+        }
+        ABI_OK(mcgpu_rccl_reduce_u64(rccl, bufs.data(), words, o, streams.data()));
+        for (int g = 0; g < n_ctx; ++g) {
+          HIP_OK(hipSetDevice(D[g].dev));
+          HIP_OK(hipEventRecord(D[g].reduced[b], D[g].reduce));
+          D[g].reduced_valid[b] = true;
+        }
+        HIP_OK(hipSetDevice(D[o].dev));
+        HIP_OK(hipStreamWaitEvent(D[o].stream, D[o].reduced[b], 0));  // the owner's tracking stream goes on with the summed tally
+        for (int g = 0; g < n_ctx; ++g)
+          if (g != o) { void* unused = nullptr; ABI_OK(mcgpu_exchange_collect(D[g].x, j, D[g].stream, &unused)); }  // bookkeeping of the local ends
+      }
       HIP_OK(hipSetDevice(D[o].dev));
       hipStream_t const so = D[o].stream;
       void* tally = nullptr;
-      ABI_OK(mcgpu_exchange_collect(D[o].x, j, so, &tally));  // the landed tallies of the other devices, added in one pass
+      ABI_OK(mcgpu_exchange_collect(D[o].x, j, so, &tally));  // exchange: the landed tallies of the other devices, added in one pass
       if (!tally) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: the owner of a projection got no tally"};
       // the reference's ASCII file: its 63 MB of text are formatted on the device (ascii_device.hip) while the tally is
       // there; the writer thread downloads and writes them while the next projection is tracked
@@ -433,9 +490,14 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
       for (int g = 0; g < n_ctx; ++g) {
         HIP_OK(hipSetDevice(D[g].dev));
         void* tally = nullptr;
+        if (use_rccl && D[g].reduced_valid[i & 1]) HIP_OK(hipStreamWaitEvent(D[g].stream, D[g].reduced[i & 1], 0));  // begin() zeroes the buffer the collective of i - 2 read
         ABI_OK(mcgpu_exchange_begin(D[g].x, i, D[g].stream, &tally));
         ABI_OK(mcgpu_launch_projection(D[g].ctx, p, mode, cur_seed, D[g].lo, D[g].hi - D[g].lo, hpt_eff, tally, D[g].stream));
         ABI_OK(mcgpu_exchange_submit(D[g].x, i, D[g].stream));
+        if (use_rccl) {
+          D[g].tally[i & 1] = tally;
+          HIP_OK(hipEventRecord(D[g].tracked[i & 1], D[g].stream));
+        }
       }
       // the owner of the previous projection, behind its own kernel i (one device: this projection)
       if (single) enqueue_reduce(i);
@@ -522,7 +584,9 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     (void)hipSetDevice(d.dev);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
     if (d.copy) (void)hipStreamSynchronize(d.copy);
+    if (d.reduce) (void)hipStreamSynchronize(d.reduce);
   }
+  if (rccl) mcgpu_rccl_destroy(rccl);
   if (D[0].dev >= 0) {
     (void)hipSetDevice(D[0].dev);
     if (probe_image) (void)hipFree(probe_image);
@@ -540,6 +604,11 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
       if (d.finalized[b]) (void)hipEventDestroy(d.finalized[b]);
     }
     if (d.copy) (void)hipStreamDestroy(d.copy);
+    if (d.reduce) (void)hipStreamDestroy(d.reduce);
+    for (int b = 0; b < 2; ++b) {
+      if (d.tracked[b]) (void)hipEventDestroy(d.tracked[b]);
+      if (d.reduced[b]) (void)hipEventDestroy(d.reduced[b]);
+    }
   }
   for (auto& d : D)  // after every device has drained: an exchange end frees memory its peers push into
     if (d.x) mcgpu_exchange_destroy(d.x);
@@ -601,6 +670,36 @@ int run_scan_sharing_projections(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_
       for (int k = 0; k < 3; ++k) ABI_OK(mcgpu_stack_create((folder + "/" + kNames[k]).c_str(), cx, (int)nz, count, sx, sy, &stacks[k]));
     }
     std::vector<mcgpu_scan_options> o((size_t)n_ctx, *opt);
+    // a time-limited run (history count below 95000 = seconds per projection): ONE calibration, on device 0, for all the shards
+    // -- each device calibrating by itself would simulate its own history count and the files would depend on who wrote them
+    {
+      long long hist_in = 0, seed = 0, hpt = 150, dev0 = -1;
+      ABI_OK(mcgpu_config_i64(ctx, "total_histories", &hist_in));
+      ABI_OK(mcgpu_config_i64(ctx, "seed", &seed));
+      ABI_OK(mcgpu_config_i64(ctx, "histories_per_thread", &hpt));
+      ABI_OK(mcgpu_config_i64(ctx, "device_id", &dev0));
+      if (!opt->histories_per_projection && hist_in < 95000 && count > 0) {
+        if (dev0 < 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: a context has no device"};
+        const int mode = opt->mode == MCGPU_MODE_COMPAT ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
+        void* probe_image = nullptr;
+        double rate = 0.0;
+        try {
+          rate = calibrate_rate(ctx, (int)dev0, first, mode, seed, hpt, (size_t)4 * nx * nz, &probe_image, nullptr);
+          HIP_OK(hipDeviceSynchronize());
+        } catch (...) {
+          if (probe_image) (void)hipFree(probe_image);
+          throw;
+        }
+        (void)hipFree(probe_image);
+        unsigned long long H = (unsigned long long)(rate * (double)hist_in);  // a device simulates a projection alone: its own rate
+        if (H < 100000ULL) H = 100000ULL;
+        for (int g = 0; g < n_ctx; ++g) o[(size_t)g].histories_per_projection = H;
+        if (opt->progress) {
+          printf("       Time-limited run: %lld s per projection at %.3e x-rays/s per device -> %llu histories per projection\n", hist_in, rate, H);
+          fflush(stdout);
+        }
+      }
+    }
     std::vector<mcgpu_scan_report> r((size_t)n_ctx);
     std::vector<int> rcs((size_t)n_ctx, 0);
     std::vector<std::string> errs((size_t)n_ctx);
@@ -674,19 +773,39 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   for (int g = 0; g < n_ctx; ++g)
     if (!ctxs[g]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null context"); return -1; }
   if (n_ctx > 1 && opt->shard == MCGPU_SHARD_PROJECTIONS) return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
-  const int rc = run_scan_sharing_histories(ctxs, n_ctx, opt, report);
-  if (rc == kExchangeUnavailable && n_ctx > 1) {
-    // no peer access / no copy-engine path between these devices: the reference's split (histories of one projection on several
-    // devices) needs one; whole projections per device need none and give the same files (SURVEY.md 8e's fallback mode)
-    if (opt->progress) {
-      // the reason, without the word the reference's log scanner takes for a failed run (cbctmc/mc/simulation.py:204)
-      std::string why = mcgpu_last_error();
-      for (size_t at = 0; at + 5 <= why.size(); ++at)
-        if (strncasecmp(why.c_str() + at, "error", 5) == 0) why.replace(at, 5, "fault");
-      for (size_t at; (at = why.find("!!")) != std::string::npos;) why.erase(at, 2);
-      printf("       Tally exchange between the devices is not available (%s): every device simulates whole projections instead\n", why.c_str());
-      fflush(stdout);
-    }
+  // Routes of the per-projection tally sum between the devices, in this order (each is tried in its set-up phase, before anything
+  // is simulated or written; every route gives the same output bytes):
+  //   1. the tally exchange (exchange.cpp: copy-engine pushes to the owner, one fused add)  -- skipped when RCCL is asked for
+  //   2. one ncclReduce per projection (reduce_rccl.cpp: north_star's collective, the reference's MPI_Reduce)
+  //   3. projection sharding: no traffic between the devices at all (SURVEY.md 8e's fallback mode)
+  const char* env_reduce = getenv("MCGPU_REDUCE");
+  // (asked for explicitly, the RCCL route also runs over ONE device -- a communicator of one rank: everything but the transport
+  // between devices is then exercised on a one-GPU box, tests/test_gpu_dropin.py)
+  const bool want_rccl = opt->reduce == MCGPU_REDUCE_RCCL || (opt->reduce == MCGPU_REDUCE_AUTO && env_reduce && !strcasecmp(env_reduce, "rccl"));
+  auto say = [&](const char* what) {
+    if (!opt->progress) return;
+    // the reason, without the word the reference's log scanner takes for a failed run (cbctmc/mc/simulation.py:204)
+    std::string why = mcgpu_last_error();
+    for (size_t at = 0; at + 5 <= why.size(); ++at)
+      if (strncasecmp(why.c_str() + at, "error", 5) == 0) why.replace(at, 5, "fault");
+    for (size_t at; (at = why.find("!!")) != std::string::npos;) why.erase(at, 2);
+    printf("       %s (%s)\n", what, why.c_str());
+    fflush(stdout);
+  };
+  int rc = want_rccl ? kExchangeUnavailable : run_scan_sharing_histories(ctxs, n_ctx, opt, report, false);
+  if (rc == kExchangeUnavailable) {
+    if (!want_rccl) say("Tally exchange between the devices is not available: trying one RCCL reduction per projection instead");
+    rc = run_scan_sharing_histories(ctxs, n_ctx, opt, report, true);
+    if (rc == 0 && opt->progress) { printf("       Detector tallies summed with one RCCL reduction (uint64, sum) per projection\n"); fflush(stdout); }
+  }
+  if (rc == kRcclUnavailable && n_ctx == 1) {
+    say("The RCCL reduction is not available: the device's own tally is the sum");
+    return run_scan_sharing_histories(ctxs, n_ctx, opt, report, false);
+  }
+  if (rc == kRcclUnavailable) {
+    // no peer access / no copy-engine path between these devices and no collective either: the reference's split (histories of
+    // one projection on several devices) needs one of them; whole projections per device need none and give the same files
+    say("The RCCL reduction is not available either: every device simulates whole projections instead");
     return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
   }
   return rc;

@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
     "mcgpu_exchange_connect_local", "mcgpu_exchange_probe", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
     "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
+    "mcgpu_rccl_create", "mcgpu_rccl_reduce_u64", "mcgpu_rccl_destroy",
 )
 
 
@@ -43,7 +44,7 @@ class ScanOptions(C.Structure):
                 ("output_folder", C.c_char_p), ("air_stack", C.c_char_p), ("air_sigma_y", C.c_double), ("air_sigma_x", C.c_double),
                 ("pixel_spacing_x", C.c_double), ("pixel_spacing_y", C.c_double),
                 ("shared_stacks", C.POINTER(C.c_void_p)), ("slice_of_projection", C.POINTER(C.c_int)), ("progress", C.c_int),
-                ("shard", C.c_int), ("projection_stride", C.c_int), ("projection_phase", C.c_int)]
+                ("shard", C.c_int), ("projection_stride", C.c_int), ("projection_phase", C.c_int), ("reduce", C.c_int)]
 
 
 class ScanReport(C.Structure):
@@ -535,14 +536,16 @@ class Context:
 
     def run_scan(self, mode="fast", first_projection=0, num_projections=0, histories=0, crop_nx=0, write_ascii=False, write_stacks=True,
                  output_folder=None, air_stack=None, air_sigma=(10.0, 10.0), pixel_spacing=(0.0, 0.0), shared_stacks=None,
-                 slice_of_projection=None, peers=(), shard="histories", projection_stride=0, projection_phase=0) -> dict:
+                 slice_of_projection=None, peers=(), shard="histories", projection_stride=0, projection_phase=0, reduce="auto") -> dict:
         """The whole projection loop as a device/host pipeline (mcgpu_run_scan); returns the timing report.
         `shared_stacks` = three open StackWriters (total, unscattered, scattered) filled by slice index (4-D scans).
         `peers` + shard="histories": the reference's split (tallies summed through the exchange); shard="projections": every
-        context simulates whole projections, nothing crosses between devices (SURVEY 8e fallback)."""
+        context simulates whole projections, nothing crosses between devices (SURVEY 8e fallback).  reduce="rccl": the tallies of the
+        peers are summed with one ncclReduce per projection instead of the exchange (then projection sharding if RCCL cannot be set up)."""
         o = ScanOptions()
         o.struct_size = C.sizeof(ScanOptions)
         o.shard = {"histories": 0, "projections": 1}[shard]
+        o.reduce = {"auto": 0, "rccl": 1}[reduce]
         o.projection_stride, o.projection_phase = int(projection_stride), int(projection_phase)
         if shared_stacks is not None:
             self._keep = ((C.c_void_p * 3)(*[s.h for s in shared_stacks]), (C.c_int * len(slice_of_projection))(*map(int, slice_of_projection)))

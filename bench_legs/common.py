@@ -1,0 +1,87 @@
+"""Workloads, their inputs, and the identity of the kernel build being measured."""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+# Algorithmic bytes per history in the REFERENCE's table layout:
+#   8 B x voxel gathers + 24 B x MFP rows + 8 B x Woodcock rows + 16 B x tally read-modify-writes,
+# event counts per history measured by the instrumented oracle on each geometry (DESIGN.md 3.1 "Roofline").
+WORKLOADS = {
+    # name: (label, algorithmic bytes per history, where the figure comes from)
+    "catphan": ("catphan604_{v}cube_1mm", 241.0, "SURVEY 8d: 8x21.26 + 24x1.84 + 8x1.47 + 16x0.93"),
+    "cirs": ("cirs_305x300x152_1mm_insert", 149.0, "SURVEY 8d: 8x8.76 + 24x2.12 + 8x1.72 + 16x0.90"),
+    "thorax": ("thorax_like_512x512x256_1mm", 356.0, "DESIGN 3.1: 8x24.12 + 24x5.36 + 8x2.93 + 16x0.69 (oracle counters, projection 0)"),
+}
+KERNEL_SOURCES = ("track_pool.inc", "track_common.inc", "device_model.hpp", "track_fast.hip")
+
+
+def kernel_source_hash() -> str:
+    """Identifies the FAST kernel build: SHA-256 over its sources and over the compiler flags of track_fast.o (the
+    CXXFLAGS / HIPFLAGS / FASTMATH lines of the Makefile)."""
+    h = hashlib.sha256()
+    csrc = ROOT / "4d-cbct-mc_amd" / "csrc"
+    for name in KERNEL_SOURCES:
+        h.update((csrc / name).read_bytes())
+    for line in (csrc / "Makefile").read_text().split("\n"):
+        if line.startswith(("CXXFLAGS", "HIPFLAGS", "FASTMATH")):
+            h.update(line.encode())
+    return h.hexdigest()[:16]
+
+def build_workload(workdir: Path, workload, histories: int, n_proj: int, engine, n_vox: int = 512):
+    """Geometry + input file in the reference's wire formats (written once, by rank 0)."""
+    import cases
+    pkg = cases.pkg
+    if workload == "catphan":
+        geo = pkg.geometry.MCCatPhan604Geometry(shape=(n_vox,) * 3, image_spacing=(1.0, 1.0, 1.0))
+    elif workload == "cirs":
+        geo = pkg.geometry.MCCIRSPhantomGeometry.from_base_geometry().place_insert()
+    elif workload == "thorax":
+        geo = pkg.geometry.MCThoraxLikeGeometry()
+    else:
+        raise SystemExit(f"unknown workload {workload}")
+    sim = pkg.simulation.MCSimulation(geo, cases.material_files(), cases.spectrum_file(), n_histories=histories, n_projections=n_proj,
+                                      angle_between_projections=360.0 / n_proj)
+    # geometry.vox (the reference's text format) + geometry.voxbin (binary sidecar the engine prefers: no 134 M-line parse)
+    return sim.prepare_simulation(workdir, compress_geometry=False, engine=engine, binary_sidecar=True)
+
+def usable_cpus() -> int:
+    """Host threads this process may actually use: scheduler affinity, capped by the cgroup CPU quota (a GPU box hands a
+    1-GPU job a share of the host, while os.cpu_count() reports every core of the machine)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+def knob_environment() -> dict:
+    """The MCGPU_* tuning knobs of this process (they select kernel variants and schedules at run time); the library path is not one."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MCGPU_") and k != "MCGPU_AMD_LIB"}
+
+def kernel_variant(workload: str, ctx=None) -> dict:
+    """Which FAST kernel the engine dispatches for a workload: the template (tile records or plain u8 volume) and the scheduler are
+    chosen when the model is uploaded (model_device.cpp), not by the kernel's sources."""
+    if ctx is None:
+        import cases
+        eng = cases.pkg.engine
+        wd = Path(tempfile.gettempdir()) / f"mcgpu_bench_{workload}_512_894"
+        if not (wd / "input.in").exists():
+            wd.mkdir(parents=True, exist_ok=True)
+            build_workload(wd, workload, 100_000_000, 894, eng)
+        with eng.create(str(wd / "input.in"), device=0) as c:
+            return kernel_variant(workload, c)
+    return {"tile_records": int(ctx.geti("tile_records")), "fast_scheduler": int(ctx.geti("fast_scheduler")), "volume_kind": int(ctx.geti("volume_kind"))}

@@ -56,7 +56,7 @@ int mcgpu_clone(const mcgpu_ctx *src, int device_id, mcgpu_ctx **out);
  * "gpu_id", "threads_per_block", "histories_per_thread", "num_projections", "enable_specific_angles",
  * "num_voxels_x|y|z", "num_pixels_x|z", "num_materials_used", "num_energy_values", "palette_size",
  * "volume_bytes_device"; of the device model (diagnostic): "volume_kind", "brick_shift", "brick_count", "bricks_mixed",
- * "bricks_exterior", "exterior_cylinder", "tile_records", "tiles_in_mixed_bricks", "sigma_bracket_shift", "lds_bytes_fast",
+ * "bricks_exterior", "exterior_cylinder", "tile_records", "fast_scheduler", "tiles_in_mixed_bricks", "sigma_bracket_shift", "lds_bytes_fast",
  * "lds_bytes_compat", "blocks_per_cu", "num_cus", "device_id". */
 int mcgpu_config_i64(const mcgpu_ctx *ctx, const char *key, long long *value);
 /* Keys: "D_angle", "initial_angle", "angularROI_0", "angularROI_1", "SRotAxisD", "vertical_translation",
@@ -183,7 +183,8 @@ int mcgpu_normalize_stack(const char *total_stack, const char *air_stack, double
 
 /* Whole-scan driver on the context's GPU: the projection loop of main() (MC-GPU_v1.3.cu:667-1056) as a pipeline --
  * track -> finalize (+ clear) on the device, double-buffered pinned copies, a writer thread for the files -- so the GPU
- * never waits for output.  Zero-initialise the struct; every field has a usable default. */
+ * never waits for output.  Zero-initialise the struct, THEN set struct_size = sizeof(mcgpu_scan_options); every other field has a
+ * usable default.  struct_size stays the first field for good: inserting anything before it would be a deliberate ABI break. */
 typedef struct mcgpu_scan_options {
   /* sizeof(mcgpu_scan_options) as the CALLER was compiled: fields the caller's header did not have yet read as zero (their
    * defaults), instead of whatever follows the shorter struct in memory.  0 is refused. */
@@ -211,9 +212,17 @@ typedef struct mcgpu_scan_options {
   /* simulate only the simulated projections number phase, phase + stride, ... of the range (0, 0 = all): what
    * MCGPU_SHARD_PROJECTIONS hands to each context; usable directly by a host that runs one mcgpu_run_scan per device */
   int projection_stride, projection_phase;
+  /* mcgpu_run_scan_multi with MCGPU_SHARD_HISTORIES: how the per-device tallies of a projection are summed (the reference's
+   * MPI_Reduce, MC-GPU_v1.3.cu:1006-1024).  MCGPU_REDUCE_AUTO (0): the tally exchange; where the devices cannot reach each other,
+   * one RCCL reduction per projection; where that is not available either, projection sharding -- unless the environment says
+   * MCGPU_REDUCE=rccl.  MCGPU_REDUCE_RCCL: one ncclReduce(uint64, sum, root = the projection's owner) per projection on a stream of
+   * its own beside the next projection's kernel (then projection sharding if RCCL cannot be set up).  Same output bytes on every route. */
+  int reduce;
 } mcgpu_scan_options;
 #define MCGPU_SHARD_HISTORIES 0
 #define MCGPU_SHARD_PROJECTIONS 1
+#define MCGPU_REDUCE_AUTO 0
+#define MCGPU_REDUCE_RCCL 1
 typedef struct mcgpu_scan_report {
   int projections;
   unsigned long long histories_per_projection;
@@ -264,6 +273,17 @@ int mcgpu_exchange_collect(mcgpu_exchange *x, long long step, void *hip_stream, 
 /* out6 = {last push [ms], last fused add [ms], pushes, collects, host seconds spent waiting for peers, bytes per push} */
 int mcgpu_exchange_stats(mcgpu_exchange *x, double out6[6]);
 void mcgpu_exchange_destroy(mcgpu_exchange *x);
+
+/* The vendor-collective route of the same sum (reduce_rccl.cpp): one communicator per device of this process (ncclCommInitAll),
+ * then per projection ONE ncclReduce(uint64, sum, root) of the devices' tallies -- the reference's MPI_Reduce(MPI_UNSIGNED_LONG_LONG,
+ * MPI_SUM, root 0) of MC-GPU_v1.3.cu:1019 without the trip through the host.  RCCL is opened on first use (dlopen), never linked.
+ * create: 0, or -1 when the route cannot be taken here (no library, a device listed twice, no path between the devices) with the
+ * reason in mcgpu_last_error().  reduce: tallies[g] is uint64[words] on device g; the sum lands in tallies[root]; the call is
+ * enqueued on hip_streams[g] (one thread drives all devices: one group). */
+typedef struct mcgpu_rccl mcgpu_rccl;
+int mcgpu_rccl_create(const int *devices, int n, mcgpu_rccl **out);
+int mcgpu_rccl_reduce_u64(mcgpu_rccl *r, void *const *tallies, size_t words, int root, void *const *hip_streams);
+void mcgpu_rccl_destroy(mcgpu_rccl *r);
 
 /* Replace the context's geometry by warp(base geometry, displacement) WITHOUT leaving the device: what
  * MCSimulation4D does per respiratory state with `MCGeometry.warp` + a new voxel file + a new engine process

@@ -20,16 +20,18 @@ def scalars(g):
     return dict(zip([str(s) for s in g["scalars_names"]], [float(v) for v in g["scalars"]]))
 
 
+def sha(a):
+    """SHA-256 of an array's bytes (as oracle/gen_fullsize_pin.py hashes tables and images)."""
+    import hashlib
+    h = hashlib.sha256()
+    a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    for k in range(0, a.size, 1 << 28):
+        h.update(a[k:k + (1 << 28)].tobytes())
+    return h.hexdigest()
+
+
 def fullsize_digests(ctx):
     """SHA-256 digests of a context's host tables in the form oracle/gen_fullsize_pin.py took them from the reference."""
-    import hashlib
-
-    def sha(a):
-        h = hashlib.sha256()
-        a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-        for k in range(0, a.size, 1 << 28):
-            h.update(a[k:k + (1 << 28)].tobytes())
-        return h.hexdigest()
 
     nv, nproj = ctx.geti("num_energy_values"), ctx.num_projections
     used = np.flatnonzero(ctx.host_table("noscco", "<i4")[:25])
@@ -44,3 +46,12 @@ def fullsize_digests(ctx):
 def fullsize_pin(workload):
     import json
     return json.loads((GOLD / "fullsize_ref_pin.json").read_text())[workload]
+
+
+def fullsize_tally_pin(workload):
+    """(pin, index, reference_value): the reference's own tallies at bench size (oracle/gen_fullsize_pin.py --tallies) and the tally
+    words in which its image differs from the portable restatement's."""
+    import json
+    pin = json.loads((GOLD / "fullsize_tally_pin.json").read_text())[workload]
+    d = load(f"fullsize_tally_diff_{workload}.npz")
+    return pin, d["index"], d["reference_value"]

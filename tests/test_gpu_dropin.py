@@ -188,10 +188,42 @@ def test_executable_falls_back_to_projection_sharding_without_an_exchange(engine
     r2 = subprocess.run([str(engine.EXE_PATH), str(b), "--devices", "0,0", "--stacks", "--crop", "128"], capture_output=True, text=True, timeout=600,
                         env=dict(os.environ, MCGPU_EXCHANGE_FAIL_PROBE="1"))
     assert r1.returncode == 0 and r2.returncode == 0, r1.stdout[-2000:] + r2.stdout[-2000:]
-    assert "every device simulates whole projections instead" in r2.stdout
+    # the whole chain: exchange (probe fails) -> one RCCL reduction per projection (refused: RCCL wants one rank per GPU, and this
+    # box lists its only device twice) -> projection sharding
+    assert "trying one RCCL reduction per projection instead" in r2.stdout
+    assert r2.stdout.index("trying one RCCL reduction") < r2.stdout.index("every device simulates whole projections instead")
     assert not re.search("(?i)error", r1.stdout) and not re.search("(?i)error", r2.stdout), r2.stdout[-1500:]
     for m in ("total", "unscattered", "scattered"):
         assert np.array_equal(engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / "two" / f"projections_{m}.mha")), m
+
+
+def test_executable_rccl_reduction_route(engine, tmp_path):
+    """`--reduce rccl`: the per-projection sum of the device tallies as ONE ncclReduce(uint64, sum, root = owner) on a stream of its own
+    beside the next projection's kernel (north_star's collective; the reference's MPI_Reduce, MC-GPU_v1.3.cu:1019).  A one-GPU box
+    cannot cross a link, but a communicator of one rank runs everything else for real: the library opened with dlopen,
+    ncclCommInitAll, the grouped ncclReduce, the events between tracking and reduce stream, the double-buffered tally.  Files and
+    stacks equal the plain run's byte for byte; with the device listed twice RCCL refuses (one rank per GPU) and the scan says so
+    and shards by projection -- same bytes again."""
+    import os
+    kw = dict(n_histories=300_000, n_projections=5, angle_between_projections=72.0)
+    dirs = {k: cases.build_case("catphan64_ct", tmp_path / k, **kw) for k in ("plain", "rccl", "rccl2")}
+    common = ["--stacks", "--crop", "128"]
+    r0 = subprocess.run([str(engine.EXE_PATH), str(dirs["plain"])] + common, capture_output=True, text=True, timeout=600)
+    r1 = subprocess.run([str(engine.EXE_PATH), str(dirs["rccl"]), "--reduce", "rccl"] + common, capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([str(engine.EXE_PATH), str(dirs["rccl2"]), "--devices", "0,0", "--reduce", "rccl"] + common, capture_output=True, text=True, timeout=600)
+    for r in (r0, r1, r2):
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert not re.search("(?i)error", r.stdout), r.stdout[-1500:]
+    assert "Detector tallies summed with one RCCL reduction (uint64, sum) per projection" in r1.stdout
+    assert "The RCCL reduction is not available either: every device simulates whole projections instead" in r2.stdout and "listed twice" in r2.stdout
+    names = sorted(f.name for f in (tmp_path / "plain").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
+    assert len(names) == 5
+    data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]
+    for k in ("rccl", "rccl2"):
+        for n in names:
+            assert data(tmp_path / "plain" / n) == data(tmp_path / k / n), (k, n)
+        for m in ("total", "unscattered", "scattered"):
+            assert np.array_equal(engine.stack_read(tmp_path / "plain" / f"projections_{m}.mha"), engine.stack_read(tmp_path / k / f"projections_{m}.mha")), (k, m)
 
 
 def test_reference_command_line_through_the_mpirun_shim(engine, tmp_path):
