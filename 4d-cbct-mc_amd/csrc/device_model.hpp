@@ -115,6 +115,7 @@ struct TrackCold {
   const unsigned short* sig_mid;  // staging sources of LdsLayout::sig_mid / sig_w (null when the brackets are off)
   const float* sig_w;
   const float* wood_coarse;       // staging source of LdsLayout::wood
+  const float* woodcock;          // FAST: the reference's Woodcock table float2[num_values] (entry_face_shell only; TrackArgs::woodcock is the COMPAT kernel's)
   int brick_palette[16];        // palette index of brick code c (c < 15)
   // dose tallies (K.cu:418-443, :1547-1563); buffers live for the whole simulation (all projections accumulate)
   unsigned long long* dose_voxels;     // ulonglong2 {Edep * 100, Edep^2} per ROI voxel, x fastest; null = tally off
@@ -141,6 +142,15 @@ struct TrackCold {
   // 3e-4 detector pixels -- visible only at the half-fan beam edge, which coincides with a pixel boundary (column 1024).
   // (-3e38, 3e38) when the aperture does not lie inside (0, pi) or differs between projections: no clamp.
   float fan_ratio_lo, fan_ratio_hi;
+  // FAST kernel: a copy of the LDS layout.  The offsets of the tables only the SERVICES read (Compton shells, spectrum, majorant, dose
+  // accumulators) are taken from here -- one scalar load where a batch starts -- instead of from the launch arguments, where each
+  // would hold a scalar register for the whole kernel (the flight step's offsets stay launch arguments)
+  LdsLayout lds;
+  // ... and copies of the launch arguments that only the services read (same reason): the 32-byte cross-section records, the energy
+  // grid, the volume's extent.  (Not the dose switches: read from memory they cost the kernel 13 vector registers of scratch.)
+  const float* mfp;
+  float e0, ide;
+  float bbox[3];
   int trade_slots;  // lanes of a wave trade their parking slots: bit 0 before flying, bit 1 before the Compton and tally/source services (MCGPU_SLOT_TRADE)
 };
 
@@ -154,6 +164,7 @@ struct TrackArgs {
   int sub_nx, sub_nxy;
   int sub_kind;              // host-side dispatch only: 0 none, 1 four-bit codes, 2 tile records
   int sched_kind;            // host-side dispatch only: FAST scheduler, 0 = per-wave pools, 1 = workgroup-level pool
+  int segment_loop;          // host-side dispatch only: FAST per-wave kernel with the flight segment as an inner loop (tissue volumes)
   int rec_nx, rec_nxy;       // tile records: cubes of 2x2x2 tiles per row / per slab (tile_record_index)
   int nx, ny, nz, nxy;
   float inv_vs[3];

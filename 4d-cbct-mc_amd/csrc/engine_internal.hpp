@@ -123,6 +123,7 @@ struct DeviceModel {
     int sched_override[5] = {-1, -1, -1, -1, -1};    // MCGPU_THRESH_{COMPTON,RAYLEIGH,NEW}, MCGPU_FLYABLE_LOW, MCGPU_SWAP_BATCH (-1: sched[])
     int slot_trade = 3, hold_q = 6;                  // MCGPU_SLOT_TRADE, MCGPU_HOLD_Q
     bool no_exterior = false;                        // MCGPU_NO_EXTERIOR (also read by the geometry builders)
+    int segment_loop = -1;                           // MCGPU_SEGMENT_LOOP: -1 chosen from the model (make_args), 0 / 1 forced
     int fast_sched = 0;                              // MCGPU_FAST_SCHED: 0 per-wave pools, 1 workgroup-level pool (fixes the LDS layout: read at upload)
   } knobs;
   std::vector<float> sig_tot_host;    // copy of mfp_tot for the bracket builder

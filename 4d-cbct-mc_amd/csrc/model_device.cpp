@@ -124,6 +124,7 @@ void read_env_knobs(DeviceModel& D) {
   k.hold_q = env_int("MCGPU_HOLD_Q", 6) & 15;
   k.no_exterior = getenv("MCGPU_NO_EXTERIOR") != nullptr;
   k.fast_sched = env_int("MCGPU_FAST_SCHED", D.knobs.fast_sched) != 0 ? 1 : 0;
+  k.segment_loop = env_int("MCGPU_SEGMENT_LOOP", -1);
   D.knobs = k;
 }
 
@@ -649,6 +650,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     cold.bricks = D.bricks;
     cold.sig_mid = D.sig_mid; cold.sig_w = D.sig_w;
     cold.wood_coarse = D.wood_coarse;
+    cold.woodcock = D.woodcock;
+    cold.lds = D.lds;
     for (int c = 0; c < 16; ++c) cold.brick_palette[c] = D.brick_palette[c];
     // dose tallies (read_input :1868-1893, init_CUDA_device :2636-2657,2694-2720)
     const SimConfig& cfg = H.cfg;
@@ -664,6 +667,8 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     }
     cold.dose_voxels = D.dose_voxels;
     cold.dose_materials = D.dose_materials;
+    cold.mfp = D.mfp; cold.e0 = H.mat.e0; cold.ide = H.mat.ide;
+    for (int k = 0; k < 3; ++k) cold.bbox[k] = H.voxels.size_bbox[k];
     for (int k = 0; k < 6; ++k) cold.dose_roi[k] = cfg.dose_roi[k];
     for (int m = 0; m < kMaxMaterials; ++m)
       if (D.compact_of[m] >= 0) cold.material_of_compact[D.compact_of[m]] = m;
@@ -752,6 +757,7 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   for (int m = 0; m < kMaxMaterials; ++m)
     if (D.compact_of[m] >= 0) { shells += std::min(H.mat.noscco[m], kMaxShells); ++used; }
   const bool many_shells = used > 0 && shells >= 20 * used;
+  A.segment_loop = D.knobs.segment_loop >= 0 ? D.knobs.segment_loop : ((A.sub_kind == 2 || many_shells) ? 1 : 0);  // track_pool.inc: kSegmentLoop
   A.thresh_compton = D.knobs.compat_thresh[0] >= 0 ? D.knobs.compat_thresh[0] : (many_shells ? 48 : 32);
   A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : (many_shells ? 8 : 4);
   A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 16 : 24);

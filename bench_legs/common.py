@@ -84,4 +84,12 @@ def kernel_variant(workload: str, ctx=None) -> dict:
             build_workload(wd, workload, 100_000_000, 894, eng)
         with eng.create(str(wd / "input.in"), device=0) as c:
             return kernel_variant(workload, c)
-    return {"tile_records": int(ctx.geti("tile_records")), "fast_scheduler": int(ctx.geti("fast_scheduler")), "volume_kind": int(ctx.geti("volume_kind"))}
+    try:
+        sched = int(ctx.geti("fast_scheduler"))
+    except Exception:  # noqa: BLE001 -- a library of an earlier round (A/B runs through MCGPU_AMD_LIB) has the per-wave pools only
+        sched = 0
+    try:
+        seg = int(ctx.geti("segment_loop"))
+    except Exception:  # noqa: BLE001
+        seg = 0
+    return {"tile_records": int(ctx.geti("tile_records")), "fast_scheduler": sched, "segment_loop": seg, "volume_kind": int(ctx.geti("volume_kind"))}

@@ -414,6 +414,30 @@ def test_fast_kernel_tallies_are_pinned(gpu_engine):
         assert got[name]["sum"] == want[name]["sum"] and got[name]["sha256"] == want[name]["sha256"], name
 
 
+def test_workgroup_level_scheduler_gives_the_pinned_tallies(gpu_engine, case_dir, monkeypatch):
+    """MCGPU_FAST_SCHED=1 runs the same physics under the workgroup-level pool (track_pool.inc: track_wg_kernel -- histories parked in
+    slots that belong to the workgroup, rings of slot ids per kind of work, full batches): measured slower than the per-wave pools
+    (profiles/r05*_wg_*), kept as an opt-in.  One RNG stream per history and integer tallies: its images are the default
+    scheduler's bit for bit -- the pinned digests -- including launches too small to fill a workgroup and ids beyond 2^32."""
+    import json
+    import sys
+    sys.path.insert(0, str(cases_root() / "tools"))
+    import gen_fast_pin
+    want = json.loads((cases_root() / "tests" / "golden" / "fast_pin.json").read_text())
+    with gpu_engine.create(case_dir("water"), device=0) as ctx:
+        assert ctx.geti("fast_scheduler") == 0
+        ref = {n: ctx.run_projection(0, n, mode="fast", seed=9, first=2 ** 32 - 50)[0] for n in (1, 63, 1000, 70_001)}
+    monkeypatch.setenv("MCGPU_FAST_SCHED", "1")
+    got = gen_fast_pin.compute()
+    for name in want:
+        assert got[name]["sum"] == want[name]["sum"] and got[name]["sha256"] == want[name]["sha256"], name
+    with gpu_engine.create(case_dir("water"), device=0) as ctx:
+        assert ctx.geti("fast_scheduler") == 1
+        for n, img in ref.items():
+            again, _, done = ctx.run_projection(0, n, mode="fast", seed=9, first=2 ** 32 - 50)
+            assert done == n and np.array_equal(again, img), n
+
+
 def cases_root():
     from pathlib import Path
     return Path(__file__).resolve().parents[1]

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Dev measurement (GPU): ONE direct A/B of the FAST kernel's random numbers.  The product seeds a lag-1 multiply-with-carry per
+history with Philox4x32-7 (track_common.inc); the yardstick build (build/ab/philox.so, -DMC_RNG_PHILOX: tools/build_variant.sh)
+evaluates Philox4x32-10 PER DRAW -- BigCrush-clean, stateless -- everywhere the kernel draws.  Same workload, same projection,
+16 runs x 4e9 histories per generator (6.4e10 each); per scatter class the detected energy per history (Student t over the
+run-to-run scatter) and the z of the 32 x 32-pixel blocks, exactly the comparison of
+tests/test_gpu_fullsize.py::test_fast_against_the_bit_exact_personality_with_4e9_histories.
+usage: python tools/rng_ab.py [workload [projection]]      (spawns itself once per library)"""
+import json, os, subprocess, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+K, N, B = 16, 4_000_000_000, 32
+
+
+def blocks(img):
+    c, nz, nx = img.shape
+    return img[:, :nz // B * B, :nx // B * B].reshape(c, nz // B, B, nx // B, B).sum(axis=(2, 4)).astype(np.float64)
+
+
+def worker(wl, p, out):
+    import bench, cases
+    eng = cases.pkg.engine
+    wd = Path(f"/tmp/mcgpu_bench_{wl}_512_894")
+    if not (wd / "input.in").exists():
+        wd.mkdir(parents=True, exist_ok=True)
+        bench.build_workload(wd, wl, int(1e8), 894, eng)
+    F, secs = [], 0.0
+    with eng.create(wd / "input.in", device=0) as ctx:
+        for k in range(K):
+            img, s, d = ctx.run_projection(p, N, mode="fast", seed=100 + k)  # seeds below 2048 (the yardstick keeps 11 bits of it)
+            F.append(blocks(img) / d)
+            secs += s
+    np.savez(out, F=np.array(F), rate=K * N / secs)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+        sys.exit(0)
+    wl = sys.argv[1] if len(sys.argv) > 1 else "thorax"
+    p = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+    res = {}
+    for name in ("product", "philox"):
+        out = f"/tmp/rng_ab_{name}.npz"
+        subprocess.run([sys.executable, __file__, "--worker", wl, str(p), out], check=True, env=dict(os.environ, MCGPU_AMD_LIB=str(ROOT / "build" / "ab" / f"{name}.so")))
+        res[name] = np.load(out)
+    F, G = res["product"]["F"], res["philox"]["F"]
+    F[:, 0, :, 1024 // B] = 0.0  # the beam-edge block column (known deviation 1), as in the test
+    G[:, 0, :, 1024 // B] = 0.0
+    ef, eg = F.sum(axis=(2, 3)), G.sum(axis=(2, 3))
+    report = {"workload": wl, "projection": p, "runs_per_generator": K, "histories_per_run": N,
+              "histories_per_s": {"product_mwc": float(res["product"]["rate"]), "philox4x32_10_per_draw": float(res["philox"]["rate"])}, "classes": {}}
+    for c, cname in enumerate(("primary", "compton", "rayleigh", "multiple")):
+        se = np.sqrt(ef[:, c].var(ddof=1) / K + eg[:, c].var(ddof=1) / K)
+        z = (ef[:, c].mean() - eg[:, c].mean()) / se
+        sb = np.sqrt(F.var(axis=0, ddof=1)[c] / K + G.var(axis=0, ddof=1)[c] / K)
+        m = (G.mean(axis=0)[c] > 0) & (sb > 0)
+        zb = (F.mean(axis=0)[c][m] - G.mean(axis=0)[c][m]) / sb[m]
+        report["classes"][cname] = {"energy_ratio_product_over_philox": float(ef[:, c].mean() / eg[:, c].mean()), "relative_sigma": float(se / eg[:, c].mean()),
+                                    "t_30_degrees_of_freedom": round(float(z), 3), "blocks": int(zb.size), "block_z_mean": round(float(zb.mean()), 4),
+                                    "block_z_std": round(float(zb.std()), 4), "block_z_max_abs": round(float(np.abs(zb).max()), 2)}
+    report["passed"] = bool(all(abs(v["t_30_degrees_of_freedom"]) < 5.0 and abs(v["block_z_mean"]) < 0.3 and 0.9 < v["block_z_std"] < 1.2 and v["block_z_max_abs"] < 6.5
+                                for v in report["classes"].values()))
+    print(json.dumps(report, indent=1))
