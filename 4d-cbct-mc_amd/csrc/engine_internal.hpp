@@ -110,7 +110,7 @@ struct DeviceModel {
   unsigned short* sig_mid = nullptr;  // cross-section brackets (FAST flight step), see upload_model
   float* sig_w = nullptr;
   int sig_shift = -1, sig_coarse = 0;
-  int sched[5] = {32, 8, 36, 12, 40};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule)
+  int sched[5] = {40, 12, 44, 12, 40};  // FAST batching thresholds {compton, rayleigh, new, flyable_low, swap_batch} (mcgpu_set_fast_schedule; re-tuned in round 5: profiles/r05p_*)
   bool sched_set = false;              // mcgpu_set_fast_schedule has been called (else the scheduler's own defaults apply)
   // Tuning knobs of the environment.  Read when the device model is built and again only by
   // mcgpu_reload_env_knobs: the launch path itself never looks at the environment and never synchronises.

@@ -264,7 +264,7 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     ABI_OK(mcgpu_config_i64(ctx, "fast_scheduler", &fast_scheduler));
     if (mode == MCGPU_MODE_FAST && fast_scheduler == 0 && total >= 20000000ULL && !getenv("MCGPU_THRESH_COMPTON") && !getenv("MCGPU_THRESH_NEW") &&
         !getenv("MCGPU_SWAP_BATCH") && !getenv("MCGPU_NO_AUTOTUNE")) {
-      static const int presets[3][5] = {{32, 8, 36, 12, 40}, {32, 4, 40, 8, 32}, {24, 8, 36, 12, 24}};
+      static const int presets[3][5] = {{40, 12, 44, 12, 40}, {32, 8, 36, 12, 40}, {36, 16, 44, 12, 44}};  // profiles/r05o_*, r05p_*
       const unsigned long long probe = 6000000ULL;
       if (!probe_image) HIP_OK(hipMalloc(&probe_image, words * 8));
       HIP_OK(hipMemsetAsync(probe_image, 0, words * 8, D[0].stream));

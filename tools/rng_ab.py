@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-K, N, B = 16, 4_000_000_000, 32
+K, N, B = int(os.environ.get("RNG_AB_RUNS", "16")), int(float(os.environ.get("RNG_AB_HISTORIES", "4e9"))), 32
 
 
 def blocks(img):
