@@ -29,9 +29,10 @@ def worker(wl, p, out):
     F, secs = [], 0.0
     with eng.create(wd / "input.in", device=0) as ctx:
         for k in range(K):
-            img, s, d = ctx.run_projection(p, N, mode="fast", seed=100 + k)  # seeds below 2048 (the yardstick keeps 11 bits of it)
+            img, s, d = ctx.run_projection(p, N, mode="fast", seed=1 + k)  # seeds below 64 (the yardstick keeps 6 bits of it)
             F.append(blocks(img) / d)
             secs += s
+    print(f"{os.environ.get('MCGPU_AMD_LIB', '?').rsplit('/', 1)[-1]}: {K} x {N:.1e} histories at {K * N / secs:.3e} /s (kernel time)", file=sys.stderr, flush=True)
     np.savez(out, F=np.array(F), rate=K * N / secs)
 
 
