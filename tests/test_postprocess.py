@@ -89,6 +89,32 @@ def test_stack_writer_and_zero_replacement(engine, tmp_path):
     assert not engine.stack_read(tmp_path / "z.mha").any()
 
 
+def test_zero_replacement_through_the_bit_masks(engine, tmp_path):
+    """Slices that hold many zeros keep one bit per element and are patched through a mapping of the file (postprocess.cpp:
+    note_zeros / mha_finish): planes whose size is no multiple of 64, half zeros, a slice with a handful of zeros (the
+    position list), a slice without any, slices written by index in shuffled order -- against numpy's
+    `np.where(stack == 0, stack[stack > 0].min(), stack)` (projection.py:131-133)."""
+    rng = np.random.default_rng(9)
+    planes = rng.uniform(1, 50, (9, 33, 70)).astype(np.float32)
+    planes[rng.uniform(size=planes.shape) < 0.5] = 0.0
+    planes[3] = rng.uniform(1, 50, (33, 70)).astype(np.float32)
+    planes[3].reshape(-1)[[0, 63, 64, 2309]] = 0.0      # few zeros, at word boundaries and at the very end
+    planes[5] = rng.uniform(1, 50, (33, 70)).astype(np.float32)  # none
+    planes[7].reshape(-1)[-70:] = 0.0                   # a whole last row (the tail word of the mask)
+    want = np.where(planes == 0, planes[planes > 0].min(), planes)
+    w = engine.StackWriter(tmp_path / "a.mha", 70, 33, 9)
+    for p in planes:
+        w.append(p)
+    assert w.finish(replace_zeros=True) == planes[planes > 0].min()
+    assert np.array_equal(engine.stack_read(tmp_path / "a.mha"), want)
+    w = engine.StackWriter(tmp_path / "b.mha", 70, 33, 9)
+    for k in rng.permutation(9):
+        w.write_slice(int(k), planes[k])
+    w.finish(replace_zeros=True)
+    assert np.array_equal(engine.stack_read(tmp_path / "b.mha"), want)
+    assert (tmp_path / "a.mha").read_bytes() == (tmp_path / "b.mha").read_bytes()
+
+
 def test_air_normalisation_matches_scipy_recipe(engine, tmp_path):
     """normalize_projections (projection.py:96-115): log(gaussian_filter(air, sigma) / projections), float32 throughout."""
     rng = np.random.default_rng(9)

@@ -3,7 +3,7 @@
 (hash of the FAST kernel's sources, bench.kernel_source_hash), the workload, the kernel VARIANT the engine dispatches for it (tile
 records or plain u8, scheduler: chosen at run time in model_device.cpp) and the MCGPU_* knobs of the collecting environment, so
 that bench.py can refuse a summary that belongs to another build, variant or tuning.  Usage: pmc_summary.py <dir with pass*/> [workload]"""
-import csv, glob, json, os, sys, time
+import csv, glob, json, os, re, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import bench
@@ -14,7 +14,8 @@ for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=
     for row in csv.DictReader(open(f)):
         if "track_" not in row["Kernel_Name"] or "kernel" not in row["Kernel_Name"]:
             continue
-        kernels.add(row["Kernel_Name"].split("(")[0])
+        m = re.search(r"track_\w+<[^>]*>", row["Kernel_Name"])
+        kernels.add(m.group(0) if m else row["Kernel_Name"])
         acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     for name, d in acc.items():
