@@ -15,7 +15,6 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
-#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -63,8 +62,7 @@ struct MhaStack {
   long data_offset = 0;
   float min_positive = std::numeric_limits<float>::infinity();
   std::vector<uint64_t> zeros;  // element indices of the exact zeros of slices that hold only a few (patched in place by finish)
-  std::vector<uint32_t> zero_count;  // exact zeros per slice
-  std::vector<uint64_t> mask;        // one bit per element of every slice that holds many zeros (allocated with the first such slice)
+  std::vector<uint32_t> zero_count;  // exact zeros per slice (a slice with many is rewritten whole by finish)
   std::vector<unsigned char> have;  // slices written so far (random-access writes of a 4-D scan)
   std::mutex mu;                    // writes by slice index may come from several scans at once (projection-sharded devices)
 };
@@ -100,39 +98,25 @@ MhaStack* mha_create(const std::string& path, int nx, int ny, int nslices, doubl
 }
 
 
-// Zero bookkeeping of one plane for the final zero replacement: minimum positive value, the number of exact zeros and one bit per
-// element (zero or not) in a single branch-free pass.  A slice with a handful of zeros keeps their positions; a slice with many (the
-// scattered stack is half zeros at 1e8 histories) keeps the bit mask -- 98 KB per 1024 x 768 slice -- so that finish can patch the
-// zeros through a mapping of the file without reading anything back (round 5; before: every such slice was read, patched and
-// written again, 0.38 s after the last kernel of an 894-projection scan, a tenth of its wall time).
+// Zero bookkeeping of one plane for the final zero replacement: minimum positive value and the number of exact zeros in one
+// branch-free pass (the scattered stack is mostly zeros at 1e8 histories: recording every position cost 5 ms per
+// projection, more than the tracking kernel); positions only when the slice holds so few that finish patches them in place.
 static constexpr size_t kFewZeros = 64;
 static void note_zeros(MhaStack* s, int k, const float* plane) {
-  const size_t n = (size_t)s->nx * s->ny, base = (size_t)k * n, words = (n + 63) / 64;
+  const size_t n = (size_t)s->nx * s->ny, base = (size_t)k * n;
   if (s->zero_count.empty()) s->zero_count.assign((size_t)s->nslices, 0);
-  std::vector<uint64_t> bits(words, 0);
   float mn = s->min_positive;
   size_t nz = 0;
-  for (size_t w = 0; w < words; ++w) {
-    const size_t i0 = w * 64, i1 = std::min(n, i0 + 64);
-    uint64_t m = 0;
-    for (size_t i = i0; i < i1; ++i) {
-      const float v = plane[i];
-      m |= (uint64_t)(v == 0.0f) << (i - i0);
-      mn = (v > 0.0f && v < mn) ? v : mn;
-    }
-    bits[w] = m;
-    nz += (size_t)__builtin_popcountll(m);
+  for (size_t i = 0; i < n; ++i) {
+    const float v = plane[i];
+    nz += (v == 0.0f);
+    mn = (v > 0.0f && v < mn) ? v : mn;
   }
   s->min_positive = mn;
   s->zero_count[(size_t)k] = (uint32_t)nz;
-  if (nz == 0) return;
-  if (nz <= kFewZeros) {
-    for (size_t w = 0; w < words; ++w)
-      for (uint64_t m = bits[w]; m; m &= m - 1) s->zeros.push_back(base + w * 64 + (size_t)__builtin_ctzll(m));
-    return;
-  }
-  if (s->mask.empty()) s->mask.assign((size_t)s->nslices * words, 0);
-  std::copy(bits.begin(), bits.end(), s->mask.begin() + (size_t)k * words);
+  if (nz > 0 && nz <= kFewZeros)
+    for (size_t i = 0; i < n; ++i)
+      if (plane[i] == 0.0f) s->zeros.push_back(base + i);
 }
 
 // Write slice k (any order, each slice once): a 4-D scan visits the projections grouped by respiratory state.
@@ -163,43 +147,45 @@ void mha_append(MhaStack* s, const float* plane) {
 float mha_finish(MhaStack* s, bool replace_zeros) {
   const float fill = s->min_positive;
   if (replace_zeros && std::isfinite(fill)) {
-    // The zero positions were recorded while the planes were written (note_zeros): they are patched through a shared mapping of
-    // the file, slice after slice on a few threads -- stores into the page cache, nothing is read back or written again.
-    const size_t n = (size_t)s->nx * s->ny, words = (n + 63) / 64;
+    // Slices that hold zeros are read, patched and written back whole (pread/pwrite, several threads: the work is
+    // page-cache copies); a slice with only a handful of zeros gets them patched in place.  The zero positions were
+    // recorded while the planes were written.
+    const size_t n = (size_t)s->nx * s->ny;
     if (s->zero_count.empty()) s->zero_count.assign((size_t)s->nslices, 0);
     const std::vector<uint32_t>& count = s->zero_count;
     std::vector<size_t> first((size_t)s->nslices + 1, 0);  // positions are recorded for the few-zero slices only
     std::sort(s->zeros.begin(), s->zeros.end());           // slices written by index arrive in any order
     for (int k = 0; k < s->nslices; ++k) first[(size_t)k + 1] = first[(size_t)k] + (count[k] <= kFewZeros ? count[k] : 0);
+    fflush(s->fp);
+    const int fd = fileno(s->fp);
     std::vector<int> dirty;
     for (int k = 0; k < s->nslices; ++k)
       if (count[k] > 0) dirty.push_back(k);
-    if (!dirty.empty()) {
-      fflush(s->fp);
-      const size_t bytes = (size_t)s->data_offset + (size_t)s->nslices * n * 4;
-      void* map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(s->fp), 0);
-      if (map == MAP_FAILED) throw Error(-3, "!!ERROR!! can not map " + s->path + " for the zero replacement");
-      float* const data = reinterpret_cast<float*>(static_cast<char*>(map) + s->data_offset);  // (unaligned by the header's length: x86 stores do not mind)
-      const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), dirty.size()}));
-      auto work = [&](int t) {
-        for (size_t d = (size_t)t; d < dirty.size(); d += (size_t)nthreads) {
-          const int k = dirty[d];
-          if (count[k] <= kFewZeros) {
-            for (size_t z = first[(size_t)k]; z < first[(size_t)k + 1]; ++z) memcpy(data + s->zeros[z], &fill, 4);
-            continue;
-          }
-          float* const p = data + (size_t)k * n;
-          const uint64_t* const mk = s->mask.data() + (size_t)k * words;
-          for (size_t w = 0; w < words; ++w)
-            for (uint64_t m = mk[w]; m; m &= m - 1) memcpy(p + w * 64 + (size_t)__builtin_ctzll(m), &fill, 4);
+    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), dirty.size()}));
+    std::vector<int> failed((size_t)nthreads, 0);
+    auto work = [&](int t) {
+      std::vector<float> buf;
+      for (size_t d = (size_t)t; d < dirty.size(); d += (size_t)nthreads) {
+        const int k = dirty[d];
+        const off_t at = (off_t)(s->data_offset + (long)((size_t)k * n * 4));
+        if (count[k] <= kFewZeros) {
+          for (size_t z = first[(size_t)k]; z < first[(size_t)k + 1]; ++z)
+            if (pwrite(fd, &fill, 4, (off_t)(s->data_offset + (long)(s->zeros[z] * 4))) != 4) failed[(size_t)t] = 1;
+          continue;
         }
-      };
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
-      work(0);
-      for (auto& th : pool) th.join();
-      if (munmap(map, bytes) != 0) throw Error(-3, "!!ERROR!! can not unmap " + s->path);
-    }
+        buf.resize(n);
+        if (pread(fd, buf.data(), n * 4, at) != (ssize_t)(n * 4)) continue;  // slice never written: reported below
+        for (float& v : buf)
+          if (v == 0.0f) v = fill;
+        if (pwrite(fd, buf.data(), n * 4, at) != (ssize_t)(n * 4)) failed[(size_t)t] = 1;
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (int f : failed)
+      if (f) throw Error(-3, "!!ERROR!! short write to " + s->path);
   }
   const bool complete = s->written == s->nslices;
   const std::string path = s->path;

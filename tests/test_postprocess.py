@@ -89,10 +89,10 @@ def test_stack_writer_and_zero_replacement(engine, tmp_path):
     assert not engine.stack_read(tmp_path / "z.mha").any()
 
 
-def test_zero_replacement_through_the_bit_masks(engine, tmp_path):
-    """Slices that hold many zeros keep one bit per element and are patched through a mapping of the file (postprocess.cpp:
-    note_zeros / mha_finish): planes whose size is no multiple of 64, half zeros, a slice with a handful of zeros (the
-    position list), a slice without any, slices written by index in shuffled order -- against numpy's
+def test_zero_replacement_of_slices_with_many_and_with_few_zeros(engine, tmp_path):
+    """mha_finish (postprocess.cpp) rewrites slices that hold many zeros whole and patches a handful in place: planes whose size is
+    no multiple of 64, half zeros, a slice with a handful of zeros (the position list), a slice without any, slices written by
+    index in shuffled order, the smallest value arriving with the last slice, a caller who wants no replacement -- against numpy's
     `np.where(stack == 0, stack[stack > 0].min(), stack)` (projection.py:131-133)."""
     rng = np.random.default_rng(9)
     planes = rng.uniform(1, 50, (9, 33, 70)).astype(np.float32)
@@ -113,6 +113,20 @@ def test_zero_replacement_through_the_bit_masks(engine, tmp_path):
     w.finish(replace_zeros=True)
     assert np.array_equal(engine.stack_read(tmp_path / "b.mha"), want)
     assert (tmp_path / "a.mha").read_bytes() == (tmp_path / "b.mha").read_bytes()
+    # a caller who wants no replacement keeps its zeros
+    w = engine.StackWriter(tmp_path / "c.mha", 70, 33, 9)
+    for p in planes:
+        w.append(p)
+    w.finish(replace_zeros=False)
+    assert np.array_equal(engine.stack_read(tmp_path / "c.mha"), planes)
+    # the smallest value arrives LAST
+    late = planes.copy()
+    late[8].reshape(-1)[5] = 0.25
+    w = engine.StackWriter(tmp_path / "d.mha", 70, 33, 9)
+    for p in late:
+        w.append(p)
+    assert w.finish(replace_zeros=True) == np.float32(0.25)
+    assert np.array_equal(engine.stack_read(tmp_path / "d.mha"), np.where(late == 0, np.float32(0.25), late))
 
 
 def test_air_normalisation_matches_scipy_recipe(engine, tmp_path):
