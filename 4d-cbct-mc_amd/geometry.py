@@ -270,9 +270,14 @@ class MCThoraxLikeGeometry(MCGeometry):
     maps every class to its nominal density, geo.py:72-74).  Body soft tissue with an adipose rim and a muscle layer,
     two lungs with vessels (blood), heart (blood + muscle wall), liver, stomach, spine (bone_100 shell, red_marrow core,
     cartilage discs), ribs (bone_050), sternum (bone_020), glands, and `n_nodules` seeded soft-tissue nodules in the
-    lungs.  Lengths scale with the shape, so reduced shapes give the same anatomy at coarser voxels."""
+    lungs.  Lengths scale with the shape, so reduced shapes give the same anatomy at coarser voxels.
 
-    def __init__(self, shape=(512, 512, 256), image_spacing=(1.0, 1.0, 1.0), seed: int = 1234, n_nodules: int = 24):
+    `bone_texture=True` gives the bones the voxel-level texture the reference's `BoneMaterialMapper` produces on a real CT
+    (geo.py:138-166): inside the bone segmentation every voxel is classed by its own HU value -- red_marrow below 150, bone_020
+    up to 300, bone_050 above, bone_100 for the one-voxel outline above 300 -- here from a seeded, smoothed random HU field
+    around each structure's nominal value, so neighbouring voxels of a rib or a vertebra differ in material."""
+
+    def __init__(self, shape=(512, 512, 256), image_spacing=(1.0, 1.0, 1.0), seed: int = 1234, n_nodules: int = 24, bone_texture: bool = False):
         rng = np.random.default_rng(seed)
         scale = [n / r for n, r in zip(shape, (512.0, 512.0, 256.0))]
         # coordinates in "1 mm voxels of the full-size phantom", origin at the volume centre
@@ -327,4 +332,22 @@ class MCThoraxLikeGeometry(MCGeometry):
         put((0, -128, 20), (26, 8, 70), "bone_020")         # sternum
         for s in (-1, 1):
             put((s * 122, -80, 60), (20, 13, 22), "glands_others", only="soft_tissue")
+        if bone_texture:
+            from scipy import ndimage
+            nominal_hu = {"red_marrow": 90.0, "bone_020": 230.0, "bone_050": 420.0, "bone_100": 700.0}
+            bone = np.zeros(shape, dtype=bool)
+            hu = np.zeros(shape, dtype=np.float32)
+            for ident, value in nominal_hu.items():
+                m = mats == material_number(ident)
+                bone |= m
+                hu[m] = value
+            sl = tuple(slice(int(lo), int(hi) + 1) for lo, hi in ((i.min(), i.max()) for i in np.nonzero(bone)))  # the bones' bounding box
+            noise = ndimage.gaussian_filter(np.random.default_rng(seed + 1).standard_normal(hu[sl].shape).astype(np.float32), 0.8)
+            hu_b = hu[sl] + np.float32(170.0 / float(noise.std())) * noise
+            mask = bone[sl]
+            outline = mask & ~ndimage.binary_erosion(mask)
+            for ident, m in (("red_marrow", mask & (hu_b < 150)), ("bone_020", mask & (hu_b >= 150) & (hu_b < 300)),
+                             ("bone_050", mask & (hu_b >= 300)), ("bone_100", outline & (hu_b >= 300))):
+                mats[sl][m] = material_number(ident)
+                dens[sl][m] = np.float32(MATERIALS_125KEV[ident])
         super().__init__(mats, dens, image_spacing)

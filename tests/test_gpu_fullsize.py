@@ -140,6 +140,31 @@ def test_thorax_compat_bit_exact_and_fast_statistical_parity(thorax512):
     _fast_vs_oracle(ctx, 223, n_gpu=200_000_000, n_cpu_batches=200_000, block=16, label="thorax512")
 
 
+def test_thorax_with_voxel_level_bone_texture(engine, tmp_path_factory, monkeypatch):
+    """the brick / tile heuristics were tuned on the smooth synthetic thorax alone.  The same thorax with the
+    bone texture the reference's BoneMaterialMapper produces on a real CT (geo.py:138-166: marrow / bone_020 / bone_050 per voxel by
+    its HU value, a one-voxel bone_100 outline) puts three and more materials into one 4x4x4 tile nine times as often, i.e. sends
+    the tile-record lookup to its junction path.  COMPAT stays bit-identical to the portable oracle, FAST within the statistical
+    tolerances of the file, both with the tile records the host chooses and with the plain voxel bytes."""
+    import bench
+    wd = tmp_path_factory.mktemp("thorax512tex")
+    inp = bench.build_workload(wd, "thorax_textured", int(1e8), 894, engine)
+    with engine.create(inp, device=0) as ctx:
+        assert ctx.geti("tile_records") == 1 and ctx.geti("num_materials_used") == 14
+        T = parity.tables_from_context(ctx)
+        img_gpu, _, done = ctx.run_projection(223, 512, mode="compat", seed=9, hpt=150)
+        img_cpu, _ = T.track(223, 9, 0, 512, 150, ol.MATH_PORTABLE, n_threads=ORACLE_THREADS)
+        assert np.array_equal(img_gpu.reshape(-1), img_cpu) and img_gpu.sum() > 0
+        _fast_vs_oracle(ctx, 223, n_gpu=200_000_000, n_cpu_batches=200_000, block=16, label="thorax512 with bone texture")
+        with_records, _, n = ctx.run_projection(600, 20_000_000, mode="fast", seed=5)
+    monkeypatch.setenv("MCGPU_TILE_RECORDS", "0")
+    with engine.create(inp, device=0) as ctx:
+        assert ctx.geti("tile_records") == 0
+        plain, _, n2 = ctx.run_projection(600, 20_000_000, mode="fast", seed=5)
+    # the lookup does not touch the random numbers: the same histories, the same tallies
+    assert n == n2 and np.array_equal(with_records, plain)
+
+
 # ------------------------------------------------------------------ configs 3 and 5: the bundled CIRS phantom at full size
 @pytest.fixture(scope="module")
 def cirs_full(engine, tmp_path_factory):
