@@ -158,6 +158,28 @@ def test_catphan_recipe_and_padding():
     assert cases.simulation.source_position_for((305.0, 300.0, 152.0)) == (152.5, -850.0, 76.0)
 
 
+def test_thorax_bone_texture_follows_the_reference_bone_mapper():
+    """`MCThoraxLikeGeometry(bone_texture=True)`: the rule of the reference's BoneMaterialMapper (geo.py:138-166) applied to a seeded HU
+    field inside the bones -- only bone voxels change, all four bone classes occur side by side, bone_100 only on the one-voxel
+    outline of the bone segmentation, every class at its nominal density, the same volume for the same seed."""
+    from scipy import ndimage
+    g = cases.pkg.geometry
+    shape = (128, 128, 64)
+    smooth = g.MCThoraxLikeGeometry(shape=shape, image_spacing=(4.0, 4.0, 4.0))
+    tex = g.MCThoraxLikeGeometry(shape=shape, image_spacing=(4.0, 4.0, 4.0), bone_texture=True)
+    again = g.MCThoraxLikeGeometry(shape=shape, image_spacing=(4.0, 4.0, 4.0), bone_texture=True)
+    assert np.array_equal(tex.materials, again.materials) and np.array_equal(tex.densities, again.densities)
+    classes = [g.material_number(k) for k in ("red_marrow", "bone_020", "bone_050", "bone_100")]
+    bone = np.isin(smooth.materials, classes)
+    assert np.array_equal(np.isin(tex.materials, classes), bone)                       # the segmentation itself is unchanged
+    assert np.array_equal(tex.materials[~bone], smooth.materials[~bone]) and (tex.materials[bone] != smooth.materials[bone]).mean() > 0.3
+    for k, ident in zip(classes, ("red_marrow", "bone_020", "bone_050", "bone_100")):
+        m = tex.materials == k
+        assert m.sum() > 50 and np.all(tex.densities[m] == np.float32(g.MATERIALS_125KEV[ident]))
+    outline = bone & ~ndimage.binary_erosion(bone)
+    assert not np.any((tex.materials == classes[3]) & ~outline)
+
+
 def test_binary_voxel_sidecar_equals_text_parse(engine, tmp_path):
     """geometry.voxbin yields exactly the host model of the text file it shadows."""
     rng = np.random.default_rng(4)
