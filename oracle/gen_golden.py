@@ -35,7 +35,7 @@ import oracle_lib as ol  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 NBATCH = {"air": 200, "water": 200, "catphan64": 400, "catphan64_ct": 100, "slab_angles": 100, "catphan64_dose": 150, "graded_u16": 100, "graded_raw": 100,
-          "cirs76": 100, "thorax64": 100, "tissue22": 100}
+          "cirs76": 100, "thorax64": 100, "tissue22": 100, "thorax128_bone": 100}
 HPT = 150
 
 

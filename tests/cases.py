@@ -110,6 +110,12 @@ def _thorax_small():
     return geometry.MCThoraxLikeGeometry(shape=(64, 64, 32), image_spacing=(8.0, 8.0, 8.0))
 
 
+def _thorax_bone_texture():
+    """The thorax with the voxel-level bone texture of the reference's BoneMaterialMapper (geo.py:138-166), 128 x 128 x 64 at 4 mm:
+    marrow / bone_020 / bone_050 / bone_100 side by side inside ribs, spine and sternum (4x4x4 tiles with three and more materials)."""
+    return geometry.MCThoraxLikeGeometry(shape=(128, 128, 64), image_spacing=(4.0, 4.0, 4.0), bone_texture=True)
+
+
 def _tissue22():
     """All 22 materials of the reference in one volume (each a 10 x 10 x 11 voxel block in a water tank, nominal densities):
     the full LDS layout (22 shell tables) and every PENELOPE table fixture are exercised."""
@@ -134,6 +140,7 @@ CASES = {
     "cirs76": (_cirs_small, dict(n_projections=3, angle_between_projections=120.0, n_histories=60_000, **SMALL_DET)),
     "thorax64": (_thorax_small, dict(n_projections=2, angle_between_projections=90.0, n_histories=60_000, **SMALL_DET)),
     "tissue22": (_tissue22, dict(n_projections=2, angle_between_projections=45.0, n_histories=60_000, **SMALL_DET)),
+    "thorax128_bone": (_thorax_bone_texture, dict(n_projections=2, angle_between_projections=100.0, n_histories=60_000, **SMALL_DET)),
     # both dose tallies on (the reference template keeps them off): ROI in 1-based inclusive voxel indices; two
     # projections, because the dose arrays accumulate over the scan
     "catphan64_dose": (_catphan_small, dict(n_projections=2, angle_between_projections=90.0, n_histories=60_000,

@@ -13,7 +13,7 @@ import parity
 pytestmark = pytest.mark.gpu
 
 CASE_BATCHES = [("air", 256), ("water", 512), ("catphan64", 512), ("catphan64_ct", 256), ("slab_angles", 256), ("graded_u16", 256),
-                ("graded_raw", 256), ("cirs76", 256), ("thorax64", 256), ("tissue22", 256)]
+                ("graded_raw", 256), ("cirs76", 256), ("thorax64", 256), ("tissue22", 256), ("thorax128_bone", 256)]
 
 
 @pytest.fixture(scope="module")
@@ -193,7 +193,7 @@ def test_lds_image_keeps_two_workgroups_per_cu_with_all_22_materials(gpu_engine,
             assert ctx.geti("sigma_bracket_shift") >= 6, name
 
 
-@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw", "cirs76", "thorax64", "tissue22"])
+@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw", "cirs76", "thorax64", "tissue22", "thorax128_bone"])
 def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
     """FAST vs oracle (LIBM math = the reference's own arithmetic): every class image, per pixel."""
     with gpu_engine.create(case_dir(name), device=0) as ctx:
@@ -240,7 +240,7 @@ def test_fast_image_is_independent_of_the_schedule(gpu_engine, case_dir, monkeyp
                 monkeypatch.delenv(k)
 
 
-@pytest.mark.parametrize("case", ["thorax64", "tissue22"])
+@pytest.mark.parametrize("case", ["thorax64", "tissue22", "thorax128_bone"])
 def test_fast_image_is_independent_of_slot_trading_segment_rule_and_brick_levels(gpu_engine, case_dir, monkeypatch, case):
     """Round-2 scheduler and lookup features, same statement as above -- identical tally WORDS required:
     slot trading (MCGPU_SLOT_TRADE 0..3: lanes re-point their LDS slots with six cross-lane permutes, the place where a
