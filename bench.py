@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="host time budget of the cpu_baseline leg (bounded sample of the same workload)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the pipelined-scan measurements after the timed region")
     ap.add_argument("--no-compat", action="store_true", help="skip the COMPAT-personality leg")
-    ap.add_argument("--no-workloads", action="store_true", help="skip the CIRS / thorax legs (configs 3-5)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the CIRS / thorax / textured-thorax legs (configs 3-5)")
     ap.add_argument("--no-fdk", action="store_true", help="skip the FDK reconstruction leg (config 4)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the exchange-vs-RCCL comparison leg after the timed region")
     ap.add_argument("--scan-projections", type=int, default=894, help="projections of the end_to_end leg")

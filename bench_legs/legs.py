@@ -126,9 +126,9 @@ def fdk_leg(pkg, device, n=894, nu=1024, nv=768, du=0.388, pad=1.0):
 
 def other_workloads(eng, torch, H, projections, device, ceilings=None):
     """Configs 3-5 under the driver's clock: the same kernel measurement (8 launches of H histories) on the bundled CIRS
-    phantom and on the patient-like thorax."""
+    phantom, on the patient-like thorax and on the same thorax with the voxel-level bone texture of the reference's bone mapper."""
     out = {}
-    for wl in ("cirs", "thorax"):
+    for wl in ("cirs", "thorax", "thorax_textured"):
         t0 = time.perf_counter()
         wd = Path(os.path.join(tempfile.gettempdir(), f"mcgpu_bench_{wl}_512_{projections}"))
         inp = wd / "input.in"
