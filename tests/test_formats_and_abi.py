@@ -328,7 +328,8 @@ def test_committed_pmc_summaries_belong_to_this_kernel_build():
     (tools/collect_round.sh) would silently turn the driver's `traffic` into null: caught here instead."""
     import json
     import bench
-    for workload, name in (("catphan", "pmc_summary_latest.json"), ("cirs", "pmc_summary_cirs.json"), ("thorax", "pmc_summary_thorax.json")):
+    for workload, name in (("catphan", "pmc_summary_latest.json"), ("cirs", "pmc_summary_cirs.json"), ("thorax", "pmc_summary_thorax.json"),
+                           ("thorax_textured", "pmc_summary_thorax_textured.json")):
         stamp = json.loads((ROOT / "profiles" / name).read_text())["_stamp"]
         assert stamp["workload"] == workload, name
         assert stamp["kernel_source_sha16"] == bench.kernel_source_hash(), f"{name} is of another kernel build: run tools/collect_round.sh on a GPU box"

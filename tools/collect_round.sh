@@ -10,7 +10,7 @@ cd "$ROOT"
 mkdir -p "$OUT"
 LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads"
 bash tools/pmc_collect.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/summary.json $OUT/pmc_summary_catphan.json; cp $OUT/pmc/summary.json profiles/pmc_summary_latest.json
-for wl in thorax cirs; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done
+for wl in thorax cirs thorax_textured; do bash tools/pmc_collect.sh $OUT/pmc_$wl --workload $wl $LIGHT > /dev/null 2>&1; cp $OUT/pmc_$wl/summary.json $OUT/pmc_summary_$wl.json; cp $OUT/pmc_$wl/summary.json profiles/pmc_summary_$wl.json; done
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 for wl in cirs thorax; do python bench.py --workload $wl --no-workloads > $OUT/bench_line_$wl.json 2> $OUT/bench_line_$wl.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
@@ -28,5 +28,5 @@ for wl in cirs thorax; do rocprofv3 --kernel-trace --stats --output-format csv -
 python tools/fast_stats.py catphan cirs thorax > $OUT/fast_section_stats.txt 2> $OUT/fast_section_stats.err
 bash tools/compat_stats.sh > /dev/null 2>&1; cp gpurun_out/compat_stats.txt $OUT/compat_section_stats.txt
 MCGPU_RNG_TEST_LOG2=24 python -m pytest tests/test_fast_rng.py -q -m gpu -s 2>&1 | grep -A3 "history ids" > $OUT/fast_rng_statistics_2p24_ids.txt
-rm -rf $OUT/prof $OUT/prof_ascii $OUT/pmc/pass* $OUT/pmc_thorax/pass* $OUT/pmc_cirs/pass*
+rm -rf $OUT/prof $OUT/prof_ascii $OUT/pmc/pass* $OUT/pmc_thorax/pass* $OUT/pmc_cirs/pass* $OUT/pmc_thorax_textured/pass*
 ls -la $OUT

@@ -16,6 +16,6 @@ for set in \
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 bench.py $ARGS > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || echo "pass $i failed"
 done
-WL=catphan; case "$ARGS" in *"--workload cirs"*) WL=cirs;; *"--workload thorax"*) WL=thorax;; esac
+WL=catphan; case "$ARGS" in *"--workload cirs"*) WL=cirs;; *"--workload thorax_textured"*) WL=thorax_textured;; *"--workload thorax"*) WL=thorax;; esac
 python3 tools/pmc_summary.py "$OUT" $WL > "$OUT/summary.json"
 cat "$OUT/summary.json"
