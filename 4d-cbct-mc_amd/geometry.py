@@ -275,7 +275,9 @@ class MCThoraxLikeGeometry(MCGeometry):
     `bone_texture=True` gives the bones the voxel-level texture the reference's `BoneMaterialMapper` produces on a real CT
     (geo.py:138-166): inside the bone segmentation every voxel is classed by its own HU value -- red_marrow below 150, bone_020
     up to 300, bone_050 above, bone_100 for the one-voxel outline above 300 -- here from a seeded, smoothed random HU field
-    around each structure's nominal value, so neighbouring voxels of a rib or a vertebra differ in material."""
+    around each structure's nominal value, so neighbouring voxels of a rib or a vertebra differ in material.  The same switch applies
+    the reference's `AirMaterialMapper` (geo.py:168-183: voxels below -900 HU become air) to a seeded HU field of the lungs around
+    -820 HU: one lung voxel in eight is air, scattered through the parenchyma as on a real CT."""
 
     def __init__(self, shape=(512, 512, 256), image_spacing=(1.0, 1.0, 1.0), seed: int = 1234, n_nodules: int = 24, bone_texture: bool = False):
         rng = np.random.default_rng(seed)
@@ -350,4 +352,10 @@ class MCThoraxLikeGeometry(MCGeometry):
                              ("bone_050", mask & (hu_b >= 300)), ("bone_100", outline & (hu_b >= 300))):
                 mats[sl][m] = material_number(ident)
                 dens[sl][m] = np.float32(MATERIALS_125KEV[ident])
+            lung = mats == material_number("lung")
+            sl = tuple(slice(int(i.min()), int(i.max()) + 1) for i in np.nonzero(lung))
+            noise = ndimage.gaussian_filter(np.random.default_rng(seed + 2).standard_normal(mats[sl].shape).astype(np.float32), 1.0)
+            air = lung[sl] & (np.float32(-820.0) + np.float32(70.0 / float(noise.std())) * noise < np.float32(-900.0))
+            mats[sl][air] = material_number("air")
+            dens[sl][air] = np.float32(MATERIALS_125KEV["air"])
         super().__init__(mats, dens, image_spacing)

@@ -24,7 +24,7 @@ WORKLOADS = {
     "cirs": ("cirs_305x300x152_1mm_insert", 149.0, "SURVEY 8d: 8x8.76 + 24x2.12 + 8x1.72 + 16x0.90"),
     "thorax": ("thorax_like_512x512x256_1mm", 356.0, "DESIGN 3.1: 8x24.12 + 24x5.36 + 8x2.93 + 16x0.69 (oracle counters, projection 0)"),
     # the thorax with the voxel-level bone texture of the reference's BoneMaterialMapper (geo.py:138-166)
-    "thorax_textured": ("thorax_like_512x512x256_1mm_bone_texture", 352.0, "8x23.87 + 24x5.29 + 8x2.91 + 16x0.68 (oracle counters, projection 0: profiles/r05t_*)"),
+    "thorax_textured": ("thorax_like_512x512x256_1mm_bone_and_lung_texture", 364.0, "8x23.98 + 24x5.76 + 8x2.90 + 16x0.68 (oracle counters, projection 0: profiles/r05w_*)"),
 }
 KERNEL_SOURCES = ("track_pool.inc", "track_common.inc", "device_model.hpp", "track_fast.hip")
 

@@ -112,7 +112,8 @@ def _thorax_small():
 
 def _thorax_bone_texture():
     """The thorax with the voxel-level bone texture of the reference's BoneMaterialMapper (geo.py:138-166), 128 x 128 x 64 at 4 mm:
-    marrow / bone_020 / bone_050 / bone_100 side by side inside ribs, spine and sternum (4x4x4 tiles with three and more materials)."""
+    marrow / bone_020 / bone_050 / bone_100 side by side inside ribs, spine and sternum (4x4x4 tiles with three and more materials),
+    air voxels scattered through the lungs (AirMaterialMapper, geo.py:168-183)."""
     return geometry.MCThoraxLikeGeometry(shape=(128, 128, 64), image_spacing=(4.0, 4.0, 4.0), bone_texture=True)
 
 

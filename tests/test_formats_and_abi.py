@@ -160,8 +160,9 @@ def test_catphan_recipe_and_padding():
 
 def test_thorax_bone_texture_follows_the_reference_bone_mapper():
     """`MCThoraxLikeGeometry(bone_texture=True)`: the rule of the reference's BoneMaterialMapper (geo.py:138-166) applied to a seeded HU
-    field inside the bones -- only bone voxels change, all four bone classes occur side by side, bone_100 only on the one-voxel
-    outline of the bone segmentation, every class at its nominal density, the same volume for the same seed."""
+    field inside the bones -- all four bone classes occur side by side, bone_100 only on the one-voxel outline of the bone
+    segmentation, every class at its nominal density -- and of its AirMaterialMapper to the lungs; nothing else changes, the same
+    volume for the same seed."""
     from scipy import ndimage
     g = cases.pkg.geometry
     shape = (128, 128, 64)
@@ -172,7 +173,11 @@ def test_thorax_bone_texture_follows_the_reference_bone_mapper():
     classes = [g.material_number(k) for k in ("red_marrow", "bone_020", "bone_050", "bone_100")]
     bone = np.isin(smooth.materials, classes)
     assert np.array_equal(np.isin(tex.materials, classes), bone)                       # the segmentation itself is unchanged
-    assert np.array_equal(tex.materials[~bone], smooth.materials[~bone]) and (tex.materials[bone] != smooth.materials[bone]).mean() > 0.3
+    lung, air = smooth.materials == g.material_number("lung"), g.material_number("air")
+    assert np.array_equal(tex.materials[~bone & ~lung], smooth.materials[~bone & ~lung]) and (tex.materials[bone] != smooth.materials[bone]).mean() > 0.3
+    # the lungs (the reference's AirMaterialMapper, geo.py:168-183): some voxels become air, nothing else happens there
+    changed = lung & (tex.materials != smooth.materials)
+    assert np.all(tex.materials[changed] == air) and np.all(tex.densities[changed] == np.float32(g.MATERIALS_125KEV["air"])) and 0.05 < changed.sum() / lung.sum() < 0.25
     for k, ident in zip(classes, ("red_marrow", "bone_020", "bone_050", "bone_100")):
         m = tex.materials == k
         assert m.sum() > 50 and np.all(tex.densities[m] == np.float32(g.MATERIALS_125KEV[ident]))
