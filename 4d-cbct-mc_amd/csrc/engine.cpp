@@ -92,6 +92,7 @@ int mcgpu_config_i64(const mcgpu_ctx* ctx, const char* key, long long* value) {
   else if (k == "sub_bricks") *value = (long long)ctx->dev.sub_n[0] * ctx->dev.sub_n[1] * ctx->dev.sub_n[2];
   else if (k == "sub_bricks_mixed") *value = ctx->dev.sub_mixed;
   else if (k == "tile_records") *value = ctx->dev.tile_rec ? 1 : 0;
+  else if (k == "sub_brick_table") *value = ctx->dev.sub ? 1 : 0;
   else if (k == "segment_loop") *value = make_args(*ctx, 0).segment_loop;  // FAST per-wave kernel variant: flight segment as an inner loop (tissue volumes)
   else if (k == "fast_scheduler") *value = ctx->dev.knobs.fast_sched;  // 0: per-wave pools, 1: workgroup-level pool (MCGPU_FAST_SCHED at upload)
   else if (k == "tiles_in_mixed_bricks") *value = ctx->dev.tiles_in_mixed_bricks;

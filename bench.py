@@ -206,7 +206,7 @@ def main():
                        "volume_kind": ["u8-palette", "u16-palette", "raw-float2"][ctx.geti("volume_kind")],
                        "volume_bytes": ctx.geti("volume_bytes_device"), "materials_used": ctx.geti("num_materials_used"),
                        "lds_bytes_per_workgroup": ctx.geti("lds_bytes_fast"), "workgroups_per_cu": ctx.geti("blocks_per_cu"),
-                       "second_level": "tile records" if ctx.geti("tile_records") else "none", "tiles_in_mixed_bricks": ctx.geti("tiles_in_mixed_bricks"),
+                       "second_level": "tile records" if ctx.geti("tile_records") else ("4-bit codes" if ctx.geti("sub_brick_table") else "none"), "tiles_in_mixed_bricks": ctx.geti("tiles_in_mixed_bricks"),
                        "fast_scheduler": "workgroup-level pool" if kernel_variant(args.workload, ctx)["fast_scheduler"] else "per-wave pools",
                        "per_gpu_value": value / world},
             # frac: the reference algorithm's bytes per history (what a history NEEDS in the reference layout) over the kernel

@@ -56,7 +56,7 @@ int mcgpu_clone(const mcgpu_ctx *src, int device_id, mcgpu_ctx **out);
  * "gpu_id", "threads_per_block", "histories_per_thread", "num_projections", "enable_specific_angles",
  * "num_voxels_x|y|z", "num_pixels_x|z", "num_materials_used", "num_energy_values", "palette_size",
  * "volume_bytes_device"; of the device model (diagnostic): "volume_kind", "brick_shift", "brick_count", "bricks_mixed",
- * "bricks_exterior", "exterior_cylinder", "tile_records", "fast_scheduler", "segment_loop", "tiles_in_mixed_bricks", "sigma_bracket_shift", "lds_bytes_fast",
+ * "bricks_exterior", "exterior_cylinder", "tile_records", "sub_brick_table", "fast_scheduler", "segment_loop", "tiles_in_mixed_bricks", "sigma_bracket_shift", "lds_bytes_fast",
  * "lds_bytes_compat", "blocks_per_cu", "num_cus", "device_id". */
 int mcgpu_config_i64(const mcgpu_ctx *ctx, const char *key, long long *value);
 /* Keys: "D_angle", "initial_angle", "angularROI_0", "angularROI_1", "SRotAxisD", "vertical_translation",
