@@ -43,15 +43,77 @@ inline unsigned int tiled_voxel(unsigned int ix, unsigned int iy, unsigned int i
 }
 // Second level of a u8 volume as 16-byte TILE RECORDS (FAST kernel, round 4): the voxels of a 4x4x4 tile take at most two palette
 // entries a, b (a material boundary) in all but a few tiles: voxel v (bit (iz&3) 16 + (iy&3) 4 + (ix&3) of `mask`) is b where the
-// bit is set, else a; kind != 0: three or more entries -- ask the tiled volume.  A flight step into a mixed brick reads the tile's
-// record INSTEAD of the voxel byte: the set of cache lines such steps touch is every tile of every mixed brick (thorax: 78 % of
-// the tissue voxels, 22 MB of 64-byte tiles against 4 MB of L2 per XCD), and at 16 bytes per tile it is a quarter of that.
-// Records of the 2x2x2 tiles of an 8^3-voxel cube are contiguous (one 128-byte line).
+// bit is set, else a.  A flight step into a mixed brick reads the tile's record INSTEAD of the voxel byte: the set of cache lines
+// such steps touch is every tile of every mixed brick (thorax: 78 % of the tissue voxels, 22 MB of 64-byte tiles against 4 MB of
+// L2 per XCD), and at 16 bytes per tile it is a quarter of that.  Records of the 2x2x2 tiles of an 8^3-voxel cube are contiguous
+// (one 128-byte line).
+// Round 5: tiles with THREE or FOUR entries -- one in 20 on a CT whose bones are classed voxel by voxel (geo.py:138-166), and each
+// of them cost a second, dependent load of the voxel byte -- are held in the same 16 bytes where one entry has the majority:
+// a = the most frequent entry, `mask` = the voxels that are NOT a, and `code` says which of b, c (d) the k-th of those voxels
+// holds (k = its rank among the set bits of the mask): one bit each for three entries (at most 30 such voxels), two bits each for
+// four (at most 15).  code bits 31:30 = 0: one bit per voxel (a two-entry tile is the case code == 0), 1: two bits, 3: none of
+// these -- ask the tiled volume.
 struct TileRecord {
-  unsigned int ab;             // a | b << 8
-  unsigned int kind;           // 0: mask valid, 1: read the voxel byte
+  unsigned int ab;             // a | b << 8 | c << 16 | d << 24
+  unsigned int code;           // see above; 0 for a tile of one or two entries
   unsigned long long mask;
 };
+constexpr unsigned int kTileAskVolume = 0xC0000000u;
+// The record of a tile from its 64 palette indices (v[i] < 0: padding of an edge tile, never addressed).  One definition for the
+// host (model_device.cpp) and the device (geometry_device.hip: the records of a warped volume).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline TileRecord encode_tile_record(const short* v) {
+  int entry[4] = {-1, -1, -1, -1}, count[4] = {0, 0, 0, 0}, n = 0;
+  bool many = false;
+  for (int i = 0; i < 64; ++i) {
+    if (v[i] < 0) continue;
+    int k = 0;
+    while (k < n && entry[k] != v[i]) ++k;
+    if (k == n) {
+      if (n == 4) { many = true; break; }
+      entry[n++] = v[i];
+    }
+    ++count[k];
+  }
+  TileRecord r{0u, 0u, 0ULL};
+  if (n == 0) return r;
+  if (!many && n <= 2) {  // the round-4 record: a = the first entry met, b = the other one
+    r.ab = (unsigned int)entry[0] | ((unsigned int)(n == 2 ? entry[1] : entry[0]) << 8);
+    for (int i = 0; i < 64; ++i)
+      if (v[i] >= 0 && v[i] != entry[0]) r.mask |= 1ULL << i;
+    return r;
+  }
+  // a = the most frequent entry (the first met among equals), the others keep their order
+  int a = 0, others = 0;
+  for (int k = 1; k < n; ++k)
+    if (count[k] > count[a]) a = k;
+  for (int k = 0; k < n; ++k)
+    if (k != a) others += count[k];
+  if (many || (n == 3 && others > 30) || (n == 4 && others > 15)) {
+    r.ab = (unsigned int)entry[0] | ((unsigned int)entry[1] << 8);
+    r.code = kTileAskVolume;
+    return r;
+  }
+  int order[3] = {0, 0, 0}, m = 0;
+  for (int k = 0; k < n; ++k)
+    if (k != a) order[m++] = k;
+  r.ab = (unsigned int)entry[a];
+  for (int j = 0; j < m; ++j) r.ab |= (unsigned int)entry[order[j]] << (8 * (j + 1));
+  const int bits = n == 3 ? 1 : 2;
+  r.code = n == 3 ? 0u : (1u << 30);
+  int rank = 0;
+  for (int i = 0; i < 64; ++i) {
+    if (v[i] < 0 || v[i] == entry[a]) continue;
+    int j = 0;
+    while (entry[order[j]] != v[i]) ++j;
+    r.mask |= 1ULL << i;
+    r.code |= (unsigned int)j << (bits * rank);
+    ++rank;
+  }
+  return r;
+}
 static_assert(sizeof(TileRecord) == 16, "one record = 16 bytes, eight per 128-byte line");
 #if defined(__HIPCC__)
 __host__ __device__

@@ -110,4 +110,18 @@ int mcgpu_kat_expf(mcgpu_ctx* ctx, int n, const float* x, float* out_exp) {
   ABI_END
 }
 
+int mcgpu_kat_tile_records(int n_tiles, const short* indices, uint32_t* out_u32) {
+  ABI_BEGIN
+  require(n_tiles > 0 && indices && out_u32, -1, "!!ERROR!! mcgpu_kat_tile_records: bad argument");
+  for (int t = 0; t < n_tiles; ++t) {
+    const TileRecord r = encode_tile_record(indices + (size_t)t * 64);
+    out_u32[4 * t + 0] = r.ab;
+    out_u32[4 * t + 1] = r.code;
+    out_u32[4 * t + 2] = (uint32_t)r.mask;
+    out_u32[4 * t + 3] = (uint32_t)(r.mask >> 32);
+  }
+  return 0;
+  ABI_END
+}
+
 }  // extern "C"

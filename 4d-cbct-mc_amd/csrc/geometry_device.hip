@@ -101,9 +101,18 @@ __global__ __launch_bounds__(256) void classify_sub_kernel(GeometryRebuild g) {
     g.sub_first[s] = mixed ? kMixed : (unsigned short)first;
     if (g.rec) {
       TileRecord r;
-      r.ab = (unsigned int)(first < 0 ? 0 : first) | ((unsigned int)(second < 0 ? (first < 0 ? 0 : first) : second) << 8);
-      r.kind = many ? 1u : 0u;
-      r.mask = many ? 0ULL : mask;
+      if (!many) {  // one or two entries: the record is already known (what encode_tile_record gives for such a tile)
+        r.ab = (unsigned int)(first < 0 ? 0 : first) | ((unsigned int)(second < 0 ? (first < 0 ? 0 : first) : second) << 8);
+        r.code = 0u;
+        r.mask = mask;
+      } else {
+        short v64[64];
+        for (int i = 0; i < 64; ++i) {
+          const int x = x0 + (i & 3), y = y0 + ((i >> 2) & 3), z = z0 + (i >> 4);
+          v64[i] = (x >= g.nx || y >= g.ny || z >= g.nz) ? (short)-1 : (short)tile[i];
+        }
+        r = encode_tile_record(v64);
+      }
       g.rec[tile_record_index((unsigned int)sx, (unsigned int)sy, (unsigned int)sz, (unsigned int)g.rn[0], (unsigned int)(g.rn[0] * g.rn[1]))] = r;
     }
   }

@@ -449,19 +449,12 @@ void upload_model(mcgpu_ctx& C, int device_id) {
         std::vector<TileRecord> rec((size_t)D.rec_n[0] * D.rec_n[1] * D.rec_n[2] * 8, TileRecord{0u, 0u, 0ULL});
         for (size_t t = 0; t < nsub; ++t) {
           const unsigned int tx = (unsigned int)(t % D.sub_n[0]), ty = (unsigned int)((t / D.sub_n[0]) % D.sub_n[1]), tz = (unsigned int)(t / ((size_t)D.sub_n[0] * D.sub_n[1]));
-          TileRecord r{0u, 0u, 0ULL};
-          int a = -1, b2 = -1;
-          for (int v = 0; v < 64 && r.kind == 0u; ++v) {
+          short v64[64];
+          for (int v = 0; v < 64; ++v) {
             const int x = (int)(tx << 2) + (v & 3), y = (int)(ty << 2) + ((v >> 2) & 3), z = (int)(tz << 2) + (v >> 4);
-            if (x >= nx || y >= ny || z >= nz) continue;  // padding of an edge tile: never addressed
-            const int e = idx8[((size_t)z * ny + y) * nx + x];
-            if (a < 0) a = e;
-            if (e == a) continue;
-            if (b2 < 0) b2 = e;
-            if (e == b2) r.mask |= 1ULL << v;
-            else r.kind = 1u;
+            v64[v] = (x >= nx || y >= ny || z >= nz) ? (short)-1 : (short)idx8[((size_t)z * ny + y) * nx + x];  // padding of an edge tile: never addressed
           }
-          r.ab = (unsigned int)(a < 0 ? 0 : a) | ((unsigned int)(b2 < 0 ? (a < 0 ? 0 : a) : b2) << 8);
+          const TileRecord r = encode_tile_record(v64);
           rec[tile_record_index(tx, ty, tz, (unsigned int)D.rec_n[0], (unsigned int)(D.rec_n[0] * D.rec_n[1]))] = r;
         }
         D.tile_rec = D.put(rec);

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
-    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_microbench", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_microbench", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_kat_tile_records", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
     "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
     "mcgpu_exchange_connect_local", "mcgpu_exchange_probe", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
     "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
@@ -142,6 +142,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     lib.mcgpu_kat_expf.argtypes = [vp, ci, vp, vp]
     lib.mcgpu_kat_f32.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.mcgpu_kat_tile_records.argtypes = [ci, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -178,6 +179,15 @@ def write_voxel_binary(path, n, spacing_cm, material_zyx: np.ndarray, density_zy
     assert m.size == d.size == int(n[0]) * int(n[1]) * int(n[2])
     _check(load_library().mcgpu_write_voxel_binary(str(path).encode(), (C.c_int * 3)(*map(int, n)), (C.c_float * 3)(*map(float, spacing_cm)),
                                                    m.ctypes.data, d.ctypes.data))
+
+
+def kat_tile_records(indices) -> np.ndarray:
+    """Tile records of `indices[n_tiles, 64]` (palette index per voxel of a 4x4x4 tile, negative = padding) as the engine builds them
+    (include/mcgpu_amd.h: mcgpu_kat_tile_records): uint32[n_tiles, 4] = entries, code, mask low, mask high."""
+    v = np.ascontiguousarray(indices, dtype=np.int16).reshape(-1, 64)
+    out = np.zeros((v.shape[0], 4), dtype=np.uint32)
+    _check(load_library().mcgpu_kat_tile_records(v.shape[0], v.ctypes.data, out.ctypes.data))
+    return out
 
 
 def voxel_sidecar_path(voxel_file) -> Path:

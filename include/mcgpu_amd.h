@@ -347,6 +347,11 @@ int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, doub
 int mcgpu_kat_expf(mcgpu_ctx *ctx, int n, const float *x, float *out_exp);
 /* float operations of the COMPAT kernel: op 0 its lean square root, 1 sqrtf, 2 its lean quotient a/b, 3 a/b, 4 shell_pz(a, b, inout) */
 int mcgpu_kat_f32(mcgpu_ctx *ctx, int op, int n, const float *a, const float *b, float *inout);
+/* The 16-byte record of a 4x4x4 tile of a u8-palette volume as the host and the device build it (csrc/device_model.hpp:
+ * encode_tile_record; no reference counterpart -- the reference gathers the voxel itself, MC-GPU_kernel_v1.3.cu:262-266).  Host code
+ * only, no context: indices[t * 64 + v] = palette index of voxel v = (iz & 3) 16 + (iy & 3) 4 + (ix & 3) of tile t, negative = padding
+ * of an edge tile; out_u32[t * 4 ..] = {entries a | b << 8 | c << 16 | d << 24, code, mask low, mask high}. */
+int mcgpu_kat_tile_records(int n_tiles, const short *indices, uint32_t *out_u32);
 
 /* ------------------------------------------------------------------------------------------------
  * Row f4: FDK reconstruction of a projection stack (what the reference obtains from `rtkfdk --hardware cuda`,

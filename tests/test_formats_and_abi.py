@@ -344,3 +344,56 @@ def test_committed_pmc_summaries_belong_to_this_kernel_build():
     assert roof["traffic"] > 1e9 and 0 < roof["frac"] < 1 and roof["bound"] == "hbm" and 0.3 < valu["lane_utilisation"] < 1
     roof, _ = bench.roofline_block("catphan", int(5e7), 2.0)  # the summaries are per 1e8-history launch
     assert roof["traffic"] is None and roof["frac"] > 0
+
+
+def _decode_tile_record(rec, bit):
+    """The FAST kernel's lookup of voxel `bit` in a tile record (csrc/track_pool.inc: flight_locate), restated: None = ask the volume."""
+    ab, code, lo, hi = (int(x) for x in rec)
+    mask = lo | (hi << 32)
+    if code >= 0xC0000000:
+        return None
+    if not (mask >> bit) & 1:
+        return ab & 0xFF
+    if code == 0:
+        return (ab >> 8) & 0xFF
+    rank = bin(mask & ((1 << bit) - 1)).count("1")
+    wide = code >> 30
+    sel = (code >> (rank << wide)) & (1 + 2 * wide)
+    return (ab >> (8 + 8 * sel)) & 0xFF
+
+
+def test_tile_records_round_trip(engine):
+    """csrc/device_model.hpp: encode_tile_record (one definition for the host builder and for the device builder of a warped volume)
+    against the kernel's lookup restated above, on random tiles of one to six palette entries with and without padding: every voxel
+    comes back, tiles of one or two entries keep the round-4 record (code 0, a = the first entry met), three entries are held in the
+    record up to 30 minority voxels, four up to 15, everything else asks the volume."""
+    rng = np.random.default_rng(11)
+    tiles, kinds = [], []
+    for n_entries in (1, 2, 3, 4, 5, 6):
+        for majority in (0.3, 0.55, 0.8, 0.95):
+            for _ in range(40):
+                pal = rng.choice(256, size=n_entries, replace=False)
+                p = np.full(n_entries, (1 - majority) / max(n_entries - 1, 1)); p[rng.integers(n_entries)] = majority if n_entries > 1 else 1.0
+                t = pal[rng.choice(n_entries, size=64, p=p / p.sum())].astype(np.int16)
+                if rng.random() < 0.3:  # an edge tile: the upper x / y / z part is padding
+                    v = np.arange(64)
+                    t[((v & 3) >= rng.integers(1, 5)) | (((v >> 2) & 3) >= rng.integers(1, 5)) | ((v >> 4) >= rng.integers(1, 5))] = -1
+                tiles.append(t)
+    tiles = np.array(tiles)
+    recs = engine.kat_tile_records(tiles)
+    held = {1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 0}
+    for t, r in zip(tiles, recs):
+        valid = t[t >= 0]
+        vals, counts = np.unique(valid, return_counts=True)
+        n = len(vals)
+        others = len(valid) - counts.max() if n else 0
+        expect_volume = n >= 5 or (n == 3 and others > 30) or (n == 4 and others > 15)
+        assert (int(r[1]) >= 0xC0000000) == expect_volume, (n, others, hex(int(r[1])))
+        if n <= 2:
+            assert r[1] == 0 and (n == 0 or (int(r[0]) & 0xFF) == valid[0])
+        if expect_volume:
+            continue
+        held[n] += 1
+        for bit in np.nonzero(t >= 0)[0]:
+            assert _decode_tile_record(r, int(bit)) == t[bit], (n, bit)
+    assert held[3] > 50 and held[4] > 30 and held[5] == held[6] == 0
