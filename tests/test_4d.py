@@ -108,7 +108,7 @@ def test_gpu_warp_equals_torch_grid_sample_fixture(engine, case_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,records", [("cirs76", "0"), ("cirs76", "1"), ("slab4d", "0"), ("slab4d", "1")])
+@pytest.mark.parametrize("case,records", [("cirs76", "0"), ("cirs76", "1"), ("slab4d", "0"), ("slab4d", "1"), ("thorax128_bone", "1")])
 def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, monkeypatch, case, records):
     """mcgpu_warp_geometry (index volume warped, both brick levels -- with `records`, the 16-byte tile records rebuilt by the
     classify kernel --, object box and Woodcock majorant rebuilt on the device) against the route through the host: warp in the
@@ -116,8 +116,8 @@ def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, 
     tables, same COMPAT tallies bit for bit, same FAST tallies."""
     monkeypatch.setenv("MCGPU_TILE_RECORDS", records)
     mats, spc = cases.material_files(), cases.spectrum_file()
-    if case == "cirs76":
-        g = cases.CASES["cirs76"][0]()
+    if case in cases.CASES:  # thorax128_bone: thousands of tiles of three and four entries, encoded by the device builder after the warp
+        g = cases.CASES[case][0]()
     else:
         g = _slab()
     rng = np.random.default_rng(5)
@@ -139,7 +139,12 @@ def test_device_geometry_warp_equals_the_host_route(engine, case_dir, tmp_path, 
         assert np.array_equal(dev.host_table("density_max").view("<f4")[:22] > 0, ref.host_table("density_max").view("<f4")[:22] > 0)
         assert np.array_equal(dev.host_table("mfp_woodcock"), ref.host_table("mfp_woodcock"))
         for key in ("bricks_mixed", "bricks_exterior", "brick_shift", "brick_count"):
-            assert dev.geti(key) == ref.geti(key), key
+            # "bricks_mixed" counts the bricks whose 4-bit code says "ask the volume": mixed ones AND homogeneous ones of a palette entry
+            # without a code of its own (only entries that fill at least one whole brick get one).  A warped context keeps the BASE
+            # volume's codes, a fresh one gives codes by the warped volume's bricks: where an entry fills a whole brick in only one of
+            # the two (thin structures: the thorax's bone outline), the counts differ -- the tallies below may not
+            if key != "bricks_mixed" or case != "thorax128_bone":
+                assert dev.geti(key) == ref.geti(key), key
         for p in range(2):
             a, _, _ = dev.run_projection(p, 300, mode="compat", seed=5 + p, hpt=100)
             b, _, _ = ref.run_projection(p, 300, mode="compat", seed=5 + p, hpt=100)
@@ -199,7 +204,12 @@ def test_device_warp_that_creates_an_exterior_names_its_background(engine, tmp_p
         dev.warp_geometry(field, frame="geometry")
         assert np.array_equal(dev.host_table("voxel_mat_dens"), ref.host_table("voxel_mat_dens"))
         for key in ("bricks_mixed", "bricks_exterior", "brick_shift", "brick_count"):
-            assert dev.geti(key) == ref.geti(key), key
+            # "bricks_mixed" counts the bricks whose 4-bit code says "ask the volume": mixed ones AND homogeneous ones of a palette entry
+            # without a code of its own (only entries that fill at least one whole brick get one).  A warped context keeps the BASE
+            # volume's codes, a fresh one gives codes by the warped volume's bricks: where an entry fills a whole brick in only one of
+            # the two (thin structures: the thorax's bone outline), the counts differ -- the tallies below may not
+            if key != "bricks_mixed" or case != "thorax128_bone":
+                assert dev.geti(key) == ref.geti(key), key
         for p in range(2):
             a, _, _ = dev.run_projection(p, 400_000, mode="fast", seed=9)
             b, _, _ = ref.run_projection(p, 400_000, mode="fast", seed=9)
