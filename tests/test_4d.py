@@ -204,12 +204,7 @@ def test_device_warp_that_creates_an_exterior_names_its_background(engine, tmp_p
         dev.warp_geometry(field, frame="geometry")
         assert np.array_equal(dev.host_table("voxel_mat_dens"), ref.host_table("voxel_mat_dens"))
         for key in ("bricks_mixed", "bricks_exterior", "brick_shift", "brick_count"):
-            # "bricks_mixed" counts the bricks whose 4-bit code says "ask the volume": mixed ones AND homogeneous ones of a palette entry
-            # without a code of its own (only entries that fill at least one whole brick get one).  A warped context keeps the BASE
-            # volume's codes, a fresh one gives codes by the warped volume's bricks: where an entry fills a whole brick in only one of
-            # the two (thin structures: the thorax's bone outline), the counts differ -- the tallies below may not
-            if key != "bricks_mixed" or case != "thorax128_bone":
-                assert dev.geti(key) == ref.geti(key), key
+            assert dev.geti(key) == ref.geti(key), key
         for p in range(2):
             a, _, _ = dev.run_projection(p, 400_000, mode="fast", seed=9)
             b, _, _ = ref.run_projection(p, 400_000, mode="fast", seed=9)
