@@ -61,8 +61,8 @@ from bench_legs.roofline import measured_ceilings, pmc_summary, roofline_block, 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: the launcher's WORLD_SIZE, else 1)")
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--histories", type=float, default=1e8, help="histories per projection per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="catphan")
     ap.add_argument("--voxels", type=int, default=512, help="catphan workload: cube edge")
