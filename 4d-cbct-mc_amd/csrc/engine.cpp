@@ -23,6 +23,7 @@ const char* mcgpu_last_error(void) { return g_last_error.c_str(); }
 int mcgpu_create(const char* input_path, int device_id, mcgpu_ctx** out) {
   ABI_BEGIN
   require(input_path && out, -1, "!!ERROR!! mcgpu_create: null argument");
+  knobs_warn_unknown();  // a misspelt MCGPU_* variable is reported, not silently ignored
   std::unique_ptr<mcgpu_ctx> c(new mcgpu_ctx);
   load_model(input_path, c->host);
   if (device_id >= 0) {
@@ -178,7 +179,7 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
   require(ctx && ctx->has_device, -1, "!!ERROR!! mcgpu_launch_projection: the context has no device (created with device_id < 0)");
   require(p >= 0 && p < ctx->host.cfg.num_projections, -1, "!!ERROR!! mcgpu_launch_projection: projection index out of range");
   require(image_dev != nullptr, -1, "!!ERROR!! mcgpu_launch_projection: null image buffer");
-  require(mode == MCGPU_MODE_FAST || mode == MCGPU_MODE_COMPAT || mode == MCGPU_MODE_FAST_STATS, -1, "!!ERROR!! mcgpu_launch_projection: unknown mode");
+  require(mode == MCGPU_MODE_FAST || mode == MCGPU_MODE_COMPAT || mode == MCGPU_MODE_FAST_STATS || mode == MCGPU_MODE_FAST_F64, -1, "!!ERROR!! mcgpu_launch_projection: unknown mode");
   DeviceModel& D = ctx->dev;
   HIP_TRY(hipSetDevice(D.device_id));
   hipStream_t stream = (hipStream_t)hip_stream;
@@ -199,9 +200,9 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
       HIP_TRY(launch_track_compat(A, (int)blocks, stream));
     } else {
       // persistent grid: exactly the resident workgroups (an over-subscribed grid would run a second, thin round).  No
-      // getenv and no synchronisation here: the scheduler's parameters were uploaded by apply_schedule.
+      // environment read and no synchronisation here: the scheduler's parameters were uploaded by apply_schedule.
       if (D.resident_fast <= 0) {
-        D.resident_fast = D.knobs.blocks_per_cu > 0 ? D.knobs.blocks_per_cu : occupancy_track_fast(A);
+        D.resident_fast = D.knobs.blocks_per_cu > 0 ? D.knobs.blocks_per_cu : std::min(occupancy_track_fast(A), occupancy_track_fast64(A));
         if (D.resident_fast <= 0) D.resident_fast = 1;
       }
       const unsigned long long want = (count + kPoolBlockThreads - 1) / kPoolBlockThreads;
@@ -217,6 +218,8 @@ int mcgpu_launch_projection(mcgpu_ctx* ctx, int p, int mode, int seed, unsigned 
 #else
         throw Error(-2, "!!ERROR!! mcgpu_launch_projection: MCGPU_MODE_FAST_STATS needs the diagnostic library (libmcgpu_amd_stats.so, MCGPU_AMD_LIB)");
 #endif
+      } else if (mode == MCGPU_MODE_FAST_F64) {
+        HIP_TRY(launch_track_fast64(A, (int)std::min(want, resident), stream));
       } else {
         HIP_TRY(launch_track_fast(A, (int)std::min(want, resident), stream));
       }

@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "../../include/mcgpu_amd.h"
+#include "knobs.hpp"
 #include "device_model.hpp"
 #include "ascii_device.hpp"
 #include "geometry_device.hpp"
@@ -28,6 +29,8 @@ namespace mcgpu {
 hipError_t launch_track_compat(const TrackArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stream);
 int occupancy_track_fast(const TrackArgs& args);
+hipError_t launch_track_fast64(const TrackArgs& args, int blocks, hipStream_t stream);  // MCGPU_MODE_FAST_F64 (track_fast64.hip)
+int occupancy_track_fast64(const TrackArgs& args);
 #if defined(MC_WITH_STATS) && MC_WITH_STATS
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);  // diagnostic library only (track_stats.o)
 #endif

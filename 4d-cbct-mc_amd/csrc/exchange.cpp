@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
+#include "knobs.hpp"
 
 namespace mcgpu {
 hipError_t launch_accumulate_many(unsigned long long* dst, const unsigned long long* const* src, int n, size_t words, hipStream_t stream);  // finalize.hip
@@ -119,8 +120,7 @@ namespace {
 // how long a rank waits for a peer's counter before it gives up with an error (MCGPU_EXCHANGE_TIMEOUT_S, default 120)
 double wait_limit_seconds() {
   static const double limit = [] {
-    const char* v = getenv("MCGPU_EXCHANGE_TIMEOUT_S");
-    const double s = v ? atof(v) : 120.0;
+    const double s = mcgpu::knob_float("MCGPU_EXCHANGE_TIMEOUT_S", 120.0);
     return s > 0.0 ? s : 120.0;
   }();
   return limit;

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
+#include "knobs.hpp"
 
 extern "C" void mcgpu_set_last_error_(const char* message);
 
@@ -383,7 +384,7 @@ extern "C" int mcgpu_fdk_reconstruct(const mcgpu_fdk_options* caller_o, const fl
     const int nu_e = nu_p + 2 * next;
     // Ramp filter: FFT (hipFFT, rows zero-extended to L >= 2 nu_p - 1: no wrap-around inside the nu_p columns that are used) or,
     // with MCGPU_FDK_DIRECT_RAMP, the direct LDS convolution (same result up to float rounding; tests compare both to the oracle)
-    const bool direct = getenv("MCGPU_FDK_DIRECT_RAMP") != nullptr;
+    const bool direct = mcgpu::knob_set("MCGPU_FDK_DIRECT_RAMP");
     // The ramp is a linear convolution evaluated as a circular one of length L.  Only the nu_p detector columns in the middle of
     // a row are ever read, and for those the lag between an output and any of the nu_e data columns is at most M = nu_p + next - 1:
     // with the kernel cut to |lag| <= M, L >= 2 M + 1 keeps every lag distinct (and L >= nu_e holds the row).  L = the smallest

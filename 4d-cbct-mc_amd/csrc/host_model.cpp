@@ -4,6 +4,7 @@
 // the reference host code so that every table is bit-identical to what MC-GPU v1.3 builds
 // from the same files.  Reference citations are docker/mcgpu/MC-GPU_v1.3.cu:<line>.
 #include "host_model.hpp"
+#include "knobs.hpp"
 
 #include <sys/stat.h>
 #include <zlib.h>
@@ -875,7 +876,7 @@ void load_model(const std::string& input_path, HostModel& m) {
     const bool have_text = stat(m.cfg.file_voxels.c_str(), &st_text) == 0;
     const bool is_side = m.cfg.file_voxels.size() > 7 && m.cfg.file_voxels.compare(m.cfg.file_voxels.size() - 7, 7, ".voxbin") == 0;
     if (is_side) load_voxel_binary(m.cfg.file_voxels, m.voxels);
-    else if (have_side && !getenv("MCGPU_IGNORE_VOXBIN") && (!have_text || st_side.st_mtime >= st_text.st_mtime)) load_voxel_binary(side, m.voxels);
+    else if (have_side && !knob_set("MCGPU_IGNORE_VOXBIN") && (!have_text || st_side.st_mtime >= st_text.st_mtime)) load_voxel_binary(side, m.voxels);
     else load_voxel_file(m.cfg.file_voxels, m.voxels);
   }
   // the dose ROI may be given larger than the volume: clip its upper corner (load_voxels, :2058-2064)

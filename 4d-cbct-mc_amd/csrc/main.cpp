@@ -40,6 +40,12 @@ int main(int argc, char** argv) {
     printf("\n\n   !!read_input ERROR!! Input file name not given as an execution parameter!! Try again...\n\n");
     return 255;
   }
+  if (argc >= 2 && !strcmp(argv[1], "--knobs")) {  // the environment knobs of the engine (csrc/knobs.cpp), then exit
+    std::vector<char> t(mcgpu_knob_table(nullptr, 0));
+    mcgpu_knob_table(t.data(), t.size());
+    printf("# name\ttype (i int, f float, b switch, s string)\tscope (K kernel variant / schedule, H host pipeline, T test hook, P Python side)\tdefault\tcurrent\twhat\n%s", t.data());
+    return 0;
+  }
   int mode = MCGPU_MODE_FAST, ngpu = 1, shard = MCGPU_SHARD_HISTORIES, reduce = MCGPU_REDUCE_AUTO;
   bool write_out = true, stacks = false;
   int crop = -1;
@@ -55,7 +61,7 @@ int main(int argc, char** argv) {
     } else if (!strcmp(argv[i], "--stacks")) stacks = true;
     else if (!strcmp(argv[i], "--crop") && i + 1 < argc) crop = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--air") && i + 1 < argc) air = argv[++i];
-    else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = !strcmp(argv[++i], "compat") ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
+    else if (!strcmp(argv[i], "--mode") && i + 1 < argc) { ++i; mode = !strcmp(argv[i], "compat") ? MCGPU_MODE_COMPAT : (!strcmp(argv[i], "fast64") ? MCGPU_MODE_FAST_F64 : MCGPU_MODE_FAST); }
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--shard") && i + 1 < argc) shard = !strcmp(argv[++i], "projections") ? MCGPU_SHARD_PROJECTIONS : MCGPU_SHARD_HISTORIES;
     else if (!strcmp(argv[i], "--reduce") && i + 1 < argc) reduce = !strcmp(argv[++i], "rccl") ? MCGPU_REDUCE_RCCL : MCGPU_REDUCE_AUTO;

@@ -57,7 +57,7 @@ void mark_exterior_region(const HostModel& H, DeviceModel& D, const std::vector<
   const float ecx = 0.5f * (box_lo[0] + box_hi[0]), ecy = 0.5f * (box_lo[1] + box_hi[1]);
   const float ea = 0.5f * (box_hi[0] - box_lo[0]), eb = 0.5f * (box_hi[1] - box_lo[1]);
   float inv[2] = {0.f, 0.f};
-  if (ea > 0.f && eb > 0.f && !getenv("MCGPU_NO_ELLIPSE")) {
+  if (ea > 0.f && eb > 0.f && !knob_set("MCGPU_NO_ELLIPSE")) {
     double s2 = 0.0;
     for (int b = 0; b < D.brick_count; ++b) {
       if (!object[(size_t)b]) continue;
@@ -108,7 +108,7 @@ void mark_exterior_region(const HostModel& H, DeviceModel& D, const std::vector<
 }
 
 void read_env_knobs(DeviceModel& D) {
-  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  auto env_int = [](const char* name, int dflt) { return knob_int(name, dflt); };
   DeviceModel::Knobs k;
   k.exterior_mode = env_int("MCGPU_EXTERIOR_MODE", 3);
   k.compat_thresh[0] = env_int("MCGPU_COMPAT_THRESH_COMPTON", -1);
@@ -122,7 +122,7 @@ void read_env_knobs(DeviceModel& D) {
   for (int i = 0; i < 5; ++i) k.sched_override[i] = env_int(kSched[i], -1);
   k.slot_trade = env_int("MCGPU_SLOT_TRADE", 3);
   k.hold_q = env_int("MCGPU_HOLD_Q", 6) & 15;
-  k.no_exterior = getenv("MCGPU_NO_EXTERIOR") != nullptr;
+  k.no_exterior = knob_set("MCGPU_NO_EXTERIOR");
   k.fast_sched = env_int("MCGPU_FAST_SCHED", D.knobs.fast_sched) != 0 ? 1 : 0;
   k.segment_loop = env_int("MCGPU_SEGMENT_LOOP", -1);
   D.knobs = k;
@@ -322,7 +322,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     }
     int k = 2;
     auto nb = [&](int n, int sh) { return (n + (1 << sh) - 1) >> sh; };
-    const char* mb = getenv("MCGPU_MAX_BRICKS");  // tuning knob: a coarser grid frees LDS
+    const char* mb = knob_str("MCGPU_MAX_BRICKS");  // tuning knob: a coarser grid frees LDS
     long max_bricks = mb ? std::min<long>(std::max<long>(atol(mb), 1), kMaxBricks) : kMaxBricks;
     {
       // The FAST kernel wants two 1024-thread workgroups per CU, i.e. an LDS image of at most 80 KB.  Everything but the
@@ -420,7 +420,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
       // -> 13.68 ms, CIRS 6.52 -> 6.25, Catphan 4.17 -> 4.09 with the table OFF.  So it is off unless MCGPU_SUB_BRICKS=1
       // asks for it (kept: it halves the fabric traffic where that is what binds, and the tests hold both routes to the
       // same tallies).
-      const char* knob = getenv("MCGPU_SUB_BRICKS");
+      const char* knob = knob_str("MCGPU_SUB_BRICKS");
       const bool off = knob ? atoi(knob) == 0 : true;
       for (size_t b = 0; b < nsub; ++b) {
         const int code = (!off && first2[b] >= 0 && first2[b] < 0x100) ? code_of[first2[b]] : 0xF;
@@ -441,7 +441,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
         hot_tiles += mixed[((size_t)bz * D.brick_n[1] + by) * D.brick_n[0] + bx] ? 1 : 0;
       }
       D.tiles_in_mixed_bricks = hot_tiles;
-      const char* knob = getenv("MCGPU_TILE_RECORDS");
+      const char* knob = knob_str("MCGPU_TILE_RECORDS");
       const bool on = knob ? atoi(knob) != 0 : hot_tiles * 64 > (8LL << 20);
       D.rec_n[0] = (D.sub_n[0] + 1) >> 1; D.rec_n[1] = (D.sub_n[1] + 1) >> 1; D.rec_n[2] = (D.sub_n[2] + 1) >> 1;
       D.tile_rec = nullptr;
@@ -576,7 +576,7 @@ void upload_model(mcgpu_ctx& C, int device_id) {
     Y.wood = take(((nv + (1 << kWoodShift) - 1) >> kWoodShift) * 4, 16);
     Y.sig_mid = Y.sig_w = off;
     D.sig_shift = -1;
-    if (!getenv("MCGPU_NO_BRACKETS") && nmat > 0) {
+    if (!knob_set("MCGPU_NO_BRACKETS") && nmat > 0) {
       const int budget = 160 * 1024 / 2;  // two 1024-thread workgroups per CU
       for (int shift = 6; shift <= 12; ++shift) {
         const int nc = (nv + (1 << shift) - 1) >> shift;

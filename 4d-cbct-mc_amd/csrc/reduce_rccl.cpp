@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
+#include "knobs.hpp"
 
 extern "C" void mcgpu_set_last_error_(const char* message);  // engine.cpp
 
@@ -56,11 +57,11 @@ extern "C" {
 int mcgpu_rccl_create(const int* devices, int n, mcgpu_rccl** out) {
   if (!devices || n < 1 || !out) return fail("!!ERROR!! mcgpu_rccl_create: bad argument");
   *out = nullptr;
-  if (getenv("MCGPU_RCCL_FAIL")) return fail("!!ERROR!! RCCL reduction: failure requested (MCGPU_RCCL_FAIL)");  // test hook of the fallback chain
+  if (mcgpu::knob_set("MCGPU_RCCL_FAIL")) return fail("!!ERROR!! RCCL reduction: failure requested (MCGPU_RCCL_FAIL)");  // test hook of the fallback chain
   for (int a = 0; a < n; ++a)
     for (int b = a + 1; b < n; ++b)
       if (devices[a] == devices[b]) return fail("!!ERROR!! RCCL reduction: a device is listed twice (RCCL wants one rank per GPU)");
-  const char* name = getenv("MCGPU_RCCL_LIBRARY");
+  const char* name = mcgpu::knob_str("MCGPU_RCCL_LIBRARY");
   void* lib = dlopen(name ? name : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib && !name) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) return fail(std::string("!!ERROR!! RCCL reduction: cannot open the RCCL library (") + dlerror() + ")");

@@ -35,6 +35,10 @@
 #include <vector>
 
 #include "../../include/mcgpu_amd.h"
+#include "knobs.hpp"
+using mcgpu::knob_int;
+using mcgpu::knob_set;
+using mcgpu::knob_str;
 
 namespace {
 
@@ -152,7 +156,7 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     double px_x = 0, px_z = 0;
     ABI_OK(mcgpu_config_f64(ctx, "pixel_size_x_mm", &px_x));
     ABI_OK(mcgpu_config_f64(ctx, "pixel_size_z_mm", &px_z));
-    const int mode = opt->mode == MCGPU_MODE_COMPAT ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
+    const int mode = opt->mode == MCGPU_MODE_COMPAT ? MCGPU_MODE_COMPAT : (opt->mode == MCGPU_MODE_FAST_F64 ? MCGPU_MODE_FAST_F64 : MCGPU_MODE_FAST);
     const int first = opt->first_projection > 0 ? opt->first_projection : 0;
     const int range = (opt->num_projections > 0) ? opt->num_projections : (int)nproj_all - first;
     if (first + range > nproj_all || range <= 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: projection range outside the trajectory"};
@@ -202,12 +206,12 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
 
     // ---- device resources
     // pinned buffers are read by the writer thread and filled from whichever device owns the projection: portable
-    const unsigned int pinned_flags = (getenv("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent) | hipHostMallocPortable;
-    const bool ascii_on_host = getenv("MCGPU_ASCII_HOST") != nullptr;  // A/B: the threaded host formatter of report.cpp
-    if (const char* w = getenv("MCGPU_ASCII_WRITERS")) n_ascii = std::min(std::max(atoi(w), 1), kAsciiSlots);
+    const unsigned int pinned_flags = (knob_set("MCGPU_PINNED_COHERENT") ? hipHostMallocDefault : hipHostMallocNonCoherent) | hipHostMallocPortable;
+    const bool ascii_on_host = knob_set("MCGPU_ASCII_HOST");  // A/B: the threaded host formatter of report.cpp
+    if (const char* w = knob_str("MCGPU_ASCII_WRITERS")) n_ascii = std::min(std::max(atoi(w), 1), kAsciiSlots);
     const bool single = (n_ctx == 1);
     int policy = MCGPU_EXCHANGE_LOCAL | MCGPU_EXCHANGE_ROTATE;
-    if (const char* v = getenv("MCGPU_EXCHANGE_POLICY")) policy = MCGPU_EXCHANGE_LOCAL | (atoi(v) ? MCGPU_EXCHANGE_ROTATE : 0);
+    if (const char* v = knob_str("MCGPU_EXCHANGE_POLICY")) policy = MCGPU_EXCHANGE_LOCAL | (atoi(v) ? MCGPU_EXCHANGE_ROTATE : 0);
     mailboxes.assign(mcgpu_exchange_shared_bytes(n_ctx) * (size_t)(use_rccl ? n_ctx : 1), 0);
     void* const mailbox_region = mailboxes.data();
     const bool rotate_owner = (policy & MCGPU_EXCHANGE_ROTATE) != 0;
@@ -236,7 +240,7 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
       // peer access between every pair of devices, and one small copy-engine transfer into every peer's landing buffer: a node
       // on which either fails is reported with kExchangeUnavailable BEFORE anything has been simulated or written, and
       // mcgpu_run_scan_multi then shards the scan by projection instead (same output bytes, nothing crosses between devices)
-      if (n_ctx > 1 && getenv("MCGPU_EXCHANGE_FAIL_PROBE")) throw ScanError{-1, "!!ERROR!! tally exchange: probe failure requested (MCGPU_EXCHANGE_FAIL_PROBE)"};  // test hook
+      if (n_ctx > 1 && knob_set("MCGPU_EXCHANGE_FAIL_PROBE")) throw ScanError{-1, "!!ERROR!! tally exchange: probe failure requested (MCGPU_EXCHANGE_FAIL_PROBE)"};  // test hook
       for (int g = 0; g < n_ctx; ++g)
         for (int h = 0; h < n_ctx; ++h)
           if (g != h) ABI_OK(mcgpu_exchange_connect_local(D[g].x, D[h].x));
@@ -262,8 +266,8 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
     // the environment pins the knobs.
     long long fast_scheduler = 0;  // the presets are per-wave pool thresholds; the workgroup-level pool keeps its own defaults
     ABI_OK(mcgpu_config_i64(ctx, "fast_scheduler", &fast_scheduler));
-    if (mode == MCGPU_MODE_FAST && fast_scheduler == 0 && total >= 20000000ULL && !getenv("MCGPU_THRESH_COMPTON") && !getenv("MCGPU_THRESH_NEW") &&
-        !getenv("MCGPU_SWAP_BATCH") && !getenv("MCGPU_NO_AUTOTUNE")) {
+    if (mode != MCGPU_MODE_COMPAT && fast_scheduler == 0 && total >= 20000000ULL && !knob_set("MCGPU_THRESH_COMPTON") && !knob_set("MCGPU_THRESH_NEW") &&
+        !knob_set("MCGPU_SWAP_BATCH") && !knob_set("MCGPU_NO_AUTOTUNE")) {
       static const int presets[3][5] = {{40, 12, 44, 12, 40}, {32, 8, 36, 12, 40}, {36, 16, 44, 12, 44}};  // profiles/r05o_*, r05p_*
       const unsigned long long probe = 6000000ULL;
       if (!probe_image) HIP_OK(hipMalloc(&probe_image, words * 8));
@@ -680,7 +684,7 @@ int run_scan_sharing_projections(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_
       ABI_OK(mcgpu_config_i64(ctx, "device_id", &dev0));
       if (!opt->histories_per_projection && hist_in < 95000 && count > 0) {
         if (dev0 < 0) throw ScanError{-1, "!!ERROR!! mcgpu_run_scan: a context has no device"};
-        const int mode = opt->mode == MCGPU_MODE_COMPAT ? MCGPU_MODE_COMPAT : MCGPU_MODE_FAST;
+        const int mode = opt->mode == MCGPU_MODE_COMPAT ? MCGPU_MODE_COMPAT : (opt->mode == MCGPU_MODE_FAST_F64 ? MCGPU_MODE_FAST_F64 : MCGPU_MODE_FAST);
         void* probe_image = nullptr;
         double rate = 0.0;
         try {
@@ -778,7 +782,7 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   //   1. the tally exchange (exchange.cpp: copy-engine pushes to the owner, one fused add)  -- skipped when RCCL is asked for
   //   2. one ncclReduce per projection (reduce_rccl.cpp: north_star's collective, the reference's MPI_Reduce)
   //   3. projection sharding: no traffic between the devices at all (SURVEY.md 8e's fallback mode)
-  const char* env_reduce = getenv("MCGPU_REDUCE");
+  const char* env_reduce = knob_str("MCGPU_REDUCE");
   // (asked for explicitly, the RCCL route also runs over ONE device -- a communicator of one rank: everything but the transport
   // between devices is then exercised on a one-GPU box, tests/test_gpu_dropin.py)
   const bool want_rccl = opt->reduce == MCGPU_REDUCE_RCCL || (opt->reduce == MCGPU_REDUCE_AUTO && env_reduce && !strcasecmp(env_reduce, "rccl"));

@@ -13,16 +13,16 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-MODE_FAST, MODE_COMPAT, MODE_FAST_STATS = 0, 1, 2
-_MODES = {"fast": MODE_FAST, "compat": MODE_COMPAT, "stats": MODE_FAST_STATS, MODE_FAST: MODE_FAST, MODE_COMPAT: MODE_COMPAT,
-          MODE_FAST_STATS: MODE_FAST_STATS}
+MODE_FAST, MODE_COMPAT, MODE_FAST_STATS, MODE_FAST_F64 = 0, 1, 2, 3
+_MODES = {"fast": MODE_FAST, "compat": MODE_COMPAT, "stats": MODE_FAST_STATS, "fast64": MODE_FAST_F64, MODE_FAST: MODE_FAST,
+          MODE_COMPAT: MODE_COMPAT, MODE_FAST_STATS: MODE_FAST_STATS, MODE_FAST_F64: MODE_FAST_F64}
 
 LIB_PATH = Path(os.environ.get("MCGPU_AMD_LIB", Path(__file__).resolve().parent / "libmcgpu_amd.so"))  # override: A/B builds
 EXE_PATH = Path(__file__).resolve().parent / "MC-GPU_v1.3.x"
 
 # every symbol declared in include/mcgpu_amd.h
 ABI_SYMBOLS = (
-    "mcgpu_abi_version", "mcgpu_last_error", "mcgpu_create", "mcgpu_clone", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
+    "mcgpu_abi_version", "mcgpu_knob_table", "mcgpu_last_error", "mcgpu_create", "mcgpu_clone", "mcgpu_destroy", "mcgpu_config_i64", "mcgpu_config_f64",
     "mcgpu_host_table", "mcgpu_projection_file_name", "mcgpu_image_words", "mcgpu_launch_shape", "mcgpu_advance_seed",
     "mcgpu_launch_projection", "mcgpu_scheduler_stats", "mcgpu_scheduler_stats_ex", "mcgpu_last_kernel_ms", "mcgpu_clear_image", "mcgpu_run_projection",
     "mcgpu_write_projection", "mcgpu_format_projection", "mcgpu_write_formatted_projection", "mcgpu_dose_info", "mcgpu_dose_read", "mcgpu_dose_clear", "mcgpu_write_dose_report",
@@ -54,6 +54,16 @@ class ScanReport(C.Structure):
                 ("seconds_writer", C.c_double)]
 
 
+def knob_table():
+    """The engine's environment knobs (csrc/knobs.cpp) as a list of dicts {name, type, scope, default, current, what}."""
+    lib = load_library()
+    n = lib.mcgpu_knob_table(None, 0)
+    buf = C.create_string_buffer(n)
+    lib.mcgpu_knob_table(buf, n)
+    keys = ("name", "type", "scope", "default", "current", "what")
+    return [dict(zip(keys, line.split("\t"))) for line in buf.value.decode().split("\n") if line]
+
+
 class EngineError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"[{code}] {message}")
@@ -78,6 +88,8 @@ def load_library(path: Optional[os.PathLike] = None):
         raise ImportError(f"{p} lacks C-ABI symbols: {missing}")
     vp, cp, ci, cull = C.c_void_p, C.c_char_p, C.c_int, C.c_ulonglong
     lib.mcgpu_last_error.restype = cp
+    lib.mcgpu_knob_table.argtypes = [C.c_char_p, C.c_size_t]
+    lib.mcgpu_knob_table.restype = C.c_size_t
     lib.mcgpu_create.argtypes = [cp, ci, C.POINTER(vp)]
     lib.mcgpu_clone.argtypes = [vp, ci, C.POINTER(vp)]
     lib.mcgpu_destroy.argtypes = [vp]

@@ -73,8 +73,12 @@ def usable_cpus() -> int:
     return max(1, n)
 
 def knob_environment() -> dict:
-    """The MCGPU_* tuning knobs of this process (they select kernel variants and schedules at run time); the library path is not one."""
-    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MCGPU_") and k != "MCGPU_AMD_LIB"}
+    """The MCGPU_* tuning knobs of this process that select kernel variants and schedules at run time (scope K of the engine's
+    registry, csrc/knobs.cpp -- the same list `MC-GPU_v1.3.x --knobs` prints); host-pipeline knobs, test hooks and the library
+    path do not change the kernel and are not part of the stamp."""
+    import cases
+    kernel_knobs = {k["name"] for k in cases.pkg.engine.knob_table() if k["scope"] == "K"}
+    return {k: v for k, v in sorted(os.environ.items()) if k in kernel_knobs}
 
 def kernel_variant(workload: str, ctx=None) -> dict:
     """Which FAST kernel the engine dispatches for a workload: the template (tile records or plain u8 volume) and the scheduler are

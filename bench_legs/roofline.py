@@ -26,15 +26,15 @@ def pmc_summary(workload: str, ctx=None):
         return None, f"stale: summary was collected under knobs {stamp.get('knobs')}, running under {knob_environment()}"
     return d, f"{f.name} ({stamp.get('collected', '?')})"
 
-def timed_launches(ctx, torch, H, launches=8, warm=2):
-    """Mean kernel time [ms] of `launches` FAST launches of H histories (HIP events on the launch stream), after `warm` untimed."""
+def timed_launches(ctx, torch, H, launches=8, warm=2, mode="fast"):
+    """Mean kernel time [ms] of `launches` FAST (`mode`: "fast" / "fast64") launches of H histories (HIP events on the launch stream), after `warm` untimed."""
     nz, nx = ctx.detector_shape
     image = torch.zeros((4, nz, nx), dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     seed, nproj, ms = ctx.geti("seed"), ctx.num_projections, []
     for i in range(warm + launches):
         ctx.clear(image.data_ptr(), stream)
-        ctx.launch((i * 149) % nproj, image.data_ptr(), H, mode="fast", seed=seed, stream=stream)
+        ctx.launch((i * 149) % nproj, image.data_ptr(), H, mode=mode, seed=seed, stream=stream)
         t = ctx.last_kernel_ms()
         if i >= warm:
             ms.append(t)

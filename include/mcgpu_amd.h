@@ -37,8 +37,18 @@ typedef struct mcgpu_ctx mcgpu_ctx;
 #define MCGPU_MODE_COMPAT 1
 /* FAST with scheduler statistics (diagnostic build of the same kernel; see mcgpu_scheduler_stats). Not for timing. */
 #define MCGPU_MODE_FAST_STATS 2
+/* FAST with the three sub-steps the reference computes in double precision -- rotate_double (MC-GPU_kernel_v1.3.cu:1103-1148),
+ * GRAa (:1181-1246), GCOa's cdt1 / costh chain (:1329-1331, :1372, :1427) -- in double here too (32-bit deviates where the
+ * reference calls ranecu_double): the production kernel at the reference's arithmetic.  Same scheduling, same streams. */
+#define MCGPU_MODE_FAST_F64 3
 
 int mcgpu_abi_version(void);
+/* The engine's environment knobs as text: one line per knob, tab-separated {name, type (i/f/b/s), scope (K kernel variant or
+ * schedule, H host pipeline, T test hook, P Python side), default, current value, description}.  Returns the bytes the whole
+ * table needs including the NUL (call with cap = 0 to size a buffer).  No counterpart in the reference (MC-GPU_v1.3.cu reads
+ * no environment); `MC-GPU_v1.3.x --knobs` prints it.  A variable MCGPU_* that is not in the table is reported once per
+ * process on stdout when a context is created. */
+size_t mcgpu_knob_table(char *buf, size_t cap);
 const char *mcgpu_last_error(void);
 
 /* read_input + init_energy_spectrum + set_CT_trajectory + load_voxels + load_material

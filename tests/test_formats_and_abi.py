@@ -1,5 +1,6 @@
 """CPU tests: wire-format edge cases, error behaviour and the C-ABI surface (no GPU needed)."""
 import gzip
+import os
 import re
 from pathlib import Path
 
@@ -397,3 +398,40 @@ def test_tile_records_round_trip(engine):
         for bit in np.nonzero(t >= 0)[0]:
             assert _decode_tile_record(r, int(bit)) == t[bit], (n, bit)
     assert held[3] > 50 and held[4] > 30 and held[5] == held[6] == 0
+
+
+def test_environment_knobs_go_through_one_registry(engine, tmp_path):
+    """csrc/knobs.cpp is the engine's only reader of the environment: every name the sources ask for is a row of the
+    table; the table is what `MC-GPU_v1.3.x --knobs`, mcgpu_knob_table and INTEGRATION.md show; a misspelt MCGPU_* variable is
+    reported once -- in words the reference's log scanner (cbctmc/mc/simulation.py:204: any-case "error") does not take for a failure."""
+    import subprocess
+    import sys
+    csrc = ROOT / "4d-cbct-mc_amd" / "csrc"
+    sources = [f for f in csrc.iterdir() if f.suffix in (".cpp", ".hpp", ".hip", ".inc")]
+    reads = sum(len(re.findall(r"\bgetenv\s*\(", f.read_text())) for f in sources)
+    assert reads == 1, "the one environment read lives in knobs.cpp"
+    assert sum(f.read_text().count("getenv") for f in sources) <= 3
+    table = {k["name"]: k for k in engine.knob_table()}
+    asked = set()
+    for f in sources:
+        asked |= set(re.findall(r'knob_(?:str|set|int|float)\(\s*"(MCGPU_[A-Z0-9_]+)"', f.read_text()))
+        asked |= set(re.findall(r'env_int\(\s*"(MCGPU_[A-Z0-9_]+)"', f.read_text()))
+    asked |= {"MCGPU_THRESH_COMPTON", "MCGPU_THRESH_RAYLEIGH", "MCGPU_THRESH_NEW", "MCGPU_FLYABLE_LOW", "MCGPU_SWAP_BATCH"}  # read through an array of names
+    assert len(asked) >= 30 and asked <= set(table), asked - set(table)
+    assert {k for k, v in table.items() if v["scope"] in "KHT"} <= asked, "a registered engine knob nobody reads"
+    # the Python side's variables are rows too
+    for f in [ROOT / "4d-cbct-mc_amd" / "engine.py", ROOT / "tests" / "cases.py", ROOT / "tests" / "test_fast_rng.py"]:
+        for name in re.findall(r'environ(?:\.get)?[\[(]\s*"(MCGPU_[A-Z0-9_]+)"', f.read_text()):
+            assert name in table, (f.name, name)
+    integration = (ROOT / "INTEGRATION.md").read_text()
+    for name in table:
+        assert f"`{name}`" in integration, f"{name} missing from INTEGRATION.md's knob table"
+    gen = subprocess.run([sys.executable, str(ROOT / "tools" / "knob_table_md.py"), "--check"], timeout=120)
+    assert gen.returncode == 0, "INTEGRATION.md section 6 is not the registry's table: run python tools/knob_table_md.py"
+    exe = ROOT / "4d-cbct-mc_amd" / "MC-GPU_v1.3.x"
+    listed = subprocess.run([str(exe), "--knobs"], capture_output=True, text=True, timeout=60)
+    assert listed.returncode == 0 and all(name in listed.stdout for name in table)
+    env = dict(os.environ, MCGPU_THRESH_COMPTN="32", MCGPU_SWAP_BATCH="40")
+    r = subprocess.run([str(exe), str(tmp_path / "missing.in")], capture_output=True, text=True, timeout=60, env=env)
+    warn = [l for l in r.stdout.split("\n") if "MCGPU_THRESH_COMPTN" in l]
+    assert len(warn) == 1 and "ignored" in warn[0] and not re.search("(?i)error", warn[0]) and "MCGPU_SWAP_BATCH" not in r.stdout
