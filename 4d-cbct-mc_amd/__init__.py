@@ -7,9 +7,9 @@ Layout: `csrc/` holds the HIP kernels, the C++ host model and the C ABI (`includ
 the Python modules mirror the reference's host-side interface for this path
 (`cbctmc/mc/simulation.py`, `geometry.py`, `materials.py`, `defaults.py`, `projection.py`).
 """
-from . import defaults, geometry, materials, reconstruction, respiratory, sharding, simulation  # noqa: F401
+from . import defaults, geometry, materials, reconstruction, respiratory, sharding, simulation, workloads  # noqa: F401
 
-__all__ = ["defaults", "geometry", "materials", "reconstruction", "respiratory", "sharding", "simulation", "engine"]
+__all__ = ["defaults", "geometry", "materials", "reconstruction", "respiratory", "sharding", "simulation", "workloads", "engine"]
 
 
 def __getattr__(name):

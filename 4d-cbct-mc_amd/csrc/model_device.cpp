@@ -755,6 +755,13 @@ TrackArgs make_args(const mcgpu_ctx& C, int p) {
   A.thresh_rayleigh = D.knobs.compat_thresh[1] >= 0 ? D.knobs.compat_thresh[1] : (many_shells ? 8 : 4);
   A.thresh_new = D.knobs.compat_thresh[2] >= 0 ? D.knobs.compat_thresh[2] : (many_shells ? 16 : 24);
   A.thresh_take = D.knobs.compat_thresh[3] >= 0 ? D.knobs.compat_thresh[3] : 2;
+  // One source of truth: the FAST kernel reads mfp / e0 / ide / bbox / lds from TrackCold, written once in upload_model
+  // (they would otherwise sit in scalar registers for the whole persistent loop); the COMPAT kernel reads the copies above.
+  if (D.cold) {
+    const TrackCold& ch = D.cold_host;
+    require(ch.mfp == A.mfp && ch.e0 == A.e0 && ch.ide == A.ide && memcmp(ch.bbox, A.bbox, sizeof A.bbox) == 0 && memcmp(&ch.lds, &A.lds, sizeof A.lds) == 0, -9,
+            "!!ERROR!! internal: TrackCold and the launch arguments disagree on mfp / e0 / ide / bbox / lds (upload_model and make_args have drifted apart)");
+  }
   return A;
 }
 

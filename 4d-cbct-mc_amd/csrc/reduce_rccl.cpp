@@ -64,7 +64,10 @@ int mcgpu_rccl_create(const int* devices, int n, mcgpu_rccl** out) {
   const char* name = mcgpu::knob_str("MCGPU_RCCL_LIBRARY");
   void* lib = dlopen(name ? name : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib && !name) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!lib) return fail(std::string("!!ERROR!! RCCL reduction: cannot open the RCCL library (") + dlerror() + ")");
+  if (!lib) {
+    const char* why = dlerror();  // may be NULL (no pending message): never hand that to std::string
+    return fail(std::string("!!ERROR!! RCCL reduction: cannot open the RCCL library (") + (why ? why : "no reason given by dlopen") + ")");
+  }
   mcgpu_rccl* r = new mcgpu_rccl;
   r->lib = lib;
   r->n = n;
@@ -95,14 +98,18 @@ int mcgpu_rccl_create(const int* devices, int n, mcgpu_rccl** out) {
 // inside one group (one thread drives every device of the node).
 int mcgpu_rccl_reduce_u64(mcgpu_rccl* r, void* const* tallies, size_t words, int root, void* const* hip_streams) {
   if (!r || !tallies || !hip_streams || root < 0 || root >= r->n) return fail("!!ERROR!! mcgpu_rccl_reduce_u64: bad argument");
+  auto why = [&](ncclResult_t rc) { return std::string((r->error_string && rc > 0) ? r->error_string(rc) : "failed"); };
   ncclResult_t rc = r->group_start();
+  if (rc != kNcclSuccess) return fail("!!ERROR!! RCCL reduction: ncclGroupStart: " + why(rc));  // no group is open: nothing to end
+  const char* step = "ncclReduce";
   for (int g = 0; g < r->n && rc == kNcclSuccess; ++g) {
-    if (hipSetDevice(r->devices[(size_t)g]) != hipSuccess) { rc = -1; break; }
+    if (hipSetDevice(r->devices[(size_t)g]) != hipSuccess) { rc = -1; step = "hipSetDevice"; break; }
     rc = r->reduce(tallies[g], tallies[g], words, kNcclUint64, kNcclSum, root, r->comms[(size_t)g], (hipStream_t)hip_streams[g]);
   }
+  // the group was opened: it is closed whatever happened inside it (RCCL keeps per-thread group state), and the FIRST failure is reported
   const ncclResult_t rc_end = r->group_end();
-  if (rc == kNcclSuccess) rc = rc_end;
-  if (rc != kNcclSuccess) return fail(std::string("!!ERROR!! RCCL reduction: ncclReduce: ") + ((r->error_string && rc > 0) ? r->error_string(rc) : "failed"));
+  if (rc != kNcclSuccess) return fail(std::string("!!ERROR!! RCCL reduction: ") + step + ": " + why(rc));
+  if (rc_end != kNcclSuccess) return fail("!!ERROR!! RCCL reduction: ncclGroupEnd: " + why(rc_end));
   return 0;
 }
 

@@ -777,11 +777,15 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
   for (int g = 0; g < n_ctx; ++g)
     if (!ctxs[g]) { mcgpu_set_last_error_("!!ERROR!! mcgpu_run_scan: null context"); return -1; }
   if (n_ctx > 1 && opt->shard == MCGPU_SHARD_PROJECTIONS) return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
-  // Routes of the per-projection tally sum between the devices, in this order (each is tried in its set-up phase, before anything
-  // is simulated or written; every route gives the same output bytes):
-  //   1. the tally exchange (exchange.cpp: copy-engine pushes to the owner, one fused add)  -- skipped when RCCL is asked for
-  //   2. one ncclReduce per projection (reduce_rccl.cpp: north_star's collective, the reference's MPI_Reduce)
-  //   3. projection sharding: no traffic between the devices at all (SURVEY.md 8e's fallback mode)
+  // Routes of the per-projection tally sum between the devices (each is tried in its set-up phase, before anything is simulated or
+  // written; every route gives the same output bytes):
+  //   AUTO            the tally exchange (exchange.cpp: copy-engine pushes to the owner, one fused add); where the devices cannot reach
+  //                   each other: projection sharding -- no traffic between the devices at all (SURVEY.md 8e's fallback mode)
+  //   --reduce rccl   one ncclReduce per projection (reduce_rccl.cpp: north_star's collective, the reference's MPI_Reduce); where RCCL
+  //                   cannot be set up: projection sharding
+  // Round 6: AUTO no longer tries RCCL between the two.  The RCCL route has only ever run over a communicator of one
+  // rank (no node); on a node without peer access it would stage 45 MB x (n - 1) per projection through host memory, where
+  // projection sharding needs no traffic and writes the same bytes.  It is taken when asked for, and only then.
   const char* env_reduce = knob_str("MCGPU_REDUCE");
   // (asked for explicitly, the RCCL route also runs over ONE device -- a communicator of one rank: everything but the transport
   // between devices is then exercised on a one-GPU box, tests/test_gpu_dropin.py)
@@ -796,23 +800,23 @@ extern "C" int mcgpu_run_scan_multi(mcgpu_ctx* const* ctxs, int n_ctx, const mcg
     printf("       %s (%s)\n", what, why.c_str());
     fflush(stdout);
   };
-  int rc = want_rccl ? kExchangeUnavailable : run_scan_sharing_histories(ctxs, n_ctx, opt, report, false);
-  if (rc == kExchangeUnavailable) {
-    if (!want_rccl) say("Tally exchange between the devices is not available: trying one RCCL reduction per projection instead");
-    rc = run_scan_sharing_histories(ctxs, n_ctx, opt, report, true);
-    if (rc == 0 && opt->progress) { printf("       Detector tallies summed with one RCCL reduction (uint64, sum) per projection\n"); fflush(stdout); }
+  if (!want_rccl) {
+    const int rc = run_scan_sharing_histories(ctxs, n_ctx, opt, report, false);
+    if (rc != kExchangeUnavailable) return rc;
+    // no peer access / no copy-engine path between these devices: the reference's split (histories of one projection on several
+    // devices) needs a way to sum the tallies; whole projections per device need none and give the same files
+    say("Tally exchange between the devices is not available: every device simulates whole projections instead (--reduce rccl asks for one RCCL reduction per projection)");
+    return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
   }
-  if (rc == kRcclUnavailable && n_ctx == 1) {
+  const int rc = run_scan_sharing_histories(ctxs, n_ctx, opt, report, true);
+  if (rc == 0 && opt->progress) { printf("       Detector tallies summed with one RCCL reduction (uint64, sum) per projection\n"); fflush(stdout); }
+  if (rc != kRcclUnavailable) return rc;
+  if (n_ctx == 1) {
     say("The RCCL reduction is not available: the device's own tally is the sum");
     return run_scan_sharing_histories(ctxs, n_ctx, opt, report, false);
   }
-  if (rc == kRcclUnavailable) {
-    // no peer access / no copy-engine path between these devices and no collective either: the reference's split (histories of
-    // one projection on several devices) needs one of them; whole projections per device need none and give the same files
-    say("The RCCL reduction is not available either: every device simulates whole projections instead");
-    return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
-  }
-  return rc;
+  say("The RCCL reduction that was asked for is not available: every device simulates whole projections instead");
+  return run_scan_sharing_projections(ctxs, n_ctx, opt, report);
 }
 
 extern "C" int mcgpu_run_scan(mcgpu_ctx* ctx, const mcgpu_scan_options* opt, mcgpu_scan_report* report) {

@@ -46,12 +46,11 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
 
 # the names tests/ and tools/ import from this module
 from bench_legs.checks import entry_face_deficit, fast_vs_compat_check, oracle_check  # noqa: E402,F401
 from bench_legs.common import (HBM_PEAK_GBS, KERNEL_SOURCES, WORKLOADS, build_workload, kernel_source_hash, kernel_variant,  # noqa: E402,F401
-                               knob_environment, usable_cpus)
+                               knob_environment, package, usable_cpus)
 from bench_legs.cpu import cpu_baseline  # noqa: E402,F401
 from bench_legs.launch import spawn_ranks  # noqa: E402
 from bench_legs.legs import cirs_4d_leg, compat_leg, end_to_end_scan, fdk_leg, other_workloads  # noqa: E402,F401
@@ -134,9 +133,9 @@ def main():
     import torch
     rank, world, device, dist, backend, ctl, shares_gpus = init_ranks(args, torch)
 
-    import cases
     from bench_legs.multi import TallyRoute
-    eng = cases.pkg.engine
+    pkg = package()
+    eng = pkg.engine
     eng.load_library()
 
     H = int(args.histories)
@@ -159,7 +158,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- the timed region: W untimed steps, then exactly K steps between barrier + synchronize, max over ranks
-    route = TallyRoute(pkg=cases.pkg, torch=torch, dist=dist, ctl=ctl, backend=backend, rank=rank, world=world, device=device, ctx=ctx,
+    route = TallyRoute(pkg=pkg, torch=torch, dist=dist, ctl=ctl, backend=backend, rank=rank, world=world, device=device, ctx=ctx,
                        stream=stream, args=args, H=H)
     for i in range(args.warmup):
         route.step(i, False)
@@ -245,7 +244,7 @@ def main():
                 out["check"]["known_deviations"] = {"beam_edge_column": (out["check"].get("fast_vs_compat") or {}).get("beam_edge_column"), "entry_face": kd}
                 failed = failed or not (kd is None or kd["passed"])
                 if not args.no_fdk:
-                    out["fdk"] = fdk_leg(cases.pkg, device)
+                    out["fdk"] = fdk_leg(pkg, device)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only (the other ranks would idle meanwhile)
             base, img_cpu, w2_cpu, n_cpu = cpu_baseline(ctx, seconds_budget=args.cpu_seconds)
             out["cpu_baseline"] = base

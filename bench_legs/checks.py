@@ -70,6 +70,8 @@ def entry_face_deficit(ctx, runs=8, fast_histories=10_000_000_000, compat_histor
 def oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu):
     """FAST vs the oracle sample of cpu_baseline on projection 0: detected energy per history per scatter class (ratio and
     z with the oracle's measured variance) and 16x16-pixel blocks."""
+    from .common import checker_paths
+    checker_paths()
     import parity
     img_gpu, _, done = ctx.run_projection(0, H, mode="fast", seed=4242)
     img_cpu, w2_cpu = img_cpu.reshape(img_gpu.shape), w2_cpu.reshape(img_gpu.shape)

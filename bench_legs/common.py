@@ -11,7 +11,20 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+
+
+def package():
+    """The engine package (4d-cbct-mc_amd/, imported as cbctmc_amd)."""
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+def checker_paths():
+    """tests/ and oracle/ hold the CHECKERS of the bench (the CPU oracle and the statistics that compare it with the kernel); only the
+    legs that check or time the oracle put them on the import path -- `bench.py --no-cpu-baseline --no-compat` runs without them."""
+    for d in ("tests",):
+        if str(ROOT / d) not in sys.path:
+            sys.path.insert(0, str(ROOT / d))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -42,23 +55,9 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 def build_workload(workdir: Path, workload, histories: int, n_proj: int, engine, n_vox: int = 512):
-    """Geometry + input file in the reference's wire formats (written once, by rank 0)."""
-    import cases
-    pkg = cases.pkg
-    if workload == "catphan":
-        geo = pkg.geometry.MCCatPhan604Geometry(shape=(n_vox,) * 3, image_spacing=(1.0, 1.0, 1.0))
-    elif workload == "cirs":
-        geo = pkg.geometry.MCCIRSPhantomGeometry.from_base_geometry().place_insert()
-    elif workload == "thorax":
-        geo = pkg.geometry.MCThoraxLikeGeometry()
-    elif workload == "thorax_textured":
-        geo = pkg.geometry.MCThoraxLikeGeometry(bone_texture=True)
-    else:
-        raise SystemExit(f"unknown workload {workload}")
-    sim = pkg.simulation.MCSimulation(geo, cases.material_files(), cases.spectrum_file(), n_histories=histories, n_projections=n_proj,
-                                      angle_between_projections=360.0 / n_proj)
-    # geometry.vox (the reference's text format) + geometry.voxbin (binary sidecar the engine prefers: no 134 M-line parse)
-    return sim.prepare_simulation(workdir, compress_geometry=False, engine=engine, binary_sidecar=True)
+    """Geometry + input file in the reference's wire formats (written once, by rank 0): the package's own builder
+    (4d-cbct-mc_amd/workloads.py: geometry.vox, the reference's text format, + the geometry.voxbin sidecar the engine prefers)."""
+    return package().workloads.build_workload(workdir, workload, histories, n_proj, engine=engine, n_vox=n_vox)
 
 def usable_cpus() -> int:
     """Host threads this process may actually use: scheduler affinity, capped by the cgroup CPU quota (a GPU box hands a
@@ -76,16 +75,14 @@ def knob_environment() -> dict:
     """The MCGPU_* tuning knobs of this process that select kernel variants and schedules at run time (scope K of the engine's
     registry, csrc/knobs.cpp -- the same list `MC-GPU_v1.3.x --knobs` prints); host-pipeline knobs, test hooks and the library
     path do not change the kernel and are not part of the stamp."""
-    import cases
-    kernel_knobs = {k["name"] for k in cases.pkg.engine.knob_table() if k["scope"] == "K"}
+    kernel_knobs = {k["name"] for k in package().engine.knob_table() if k["scope"] == "K"}
     return {k: v for k, v in sorted(os.environ.items()) if k in kernel_knobs}
 
 def kernel_variant(workload: str, ctx=None) -> dict:
     """Which FAST kernel the engine dispatches for a workload: the template (tile records or plain u8 volume) and the scheduler are
     chosen when the model is uploaded (model_device.cpp), not by the kernel's sources."""
     if ctx is None:
-        import cases
-        eng = cases.pkg.engine
+        eng = package().engine
         wd = Path(tempfile.gettempdir()) / f"mcgpu_bench_{workload}_512_894"
         if not (wd / "input.in").exists():
             wd.mkdir(parents=True, exist_ok=True)

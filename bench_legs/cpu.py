@@ -12,6 +12,8 @@ def cpu_baseline(ctx, seconds_budget: float = 16.0):
     """The restated CPU oracle (oracle/mcgpu_oracle.c, LIBM math == reference arithmetic; the loop being timed is the
     reference's MC-GPU_v1.3.cu:913-958) on a bounded sample of the same workload, on this host's cores.  Reported, never the
     target.  Also returns the sample's image and its sum of squared weights (for `check`)."""
+    from .common import checker_paths
+    checker_paths()
     import oracle_lib as ol
     import parity
     T = parity.tables_from_context(ctx)

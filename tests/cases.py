@@ -1,7 +1,7 @@
 """Shared test-case builder (test infrastructure): small geometries + `.in` files on disk.
 
 Material numbering in the reduced cases follows the reference's 22-material order; all 22 PENELOPE
-tables of the reference are committed as fixtures (tests/golden/materials/*.mcgpu.xz).
+tables of the reference ship with the package (4d-cbct-mc_amd/assets/materials/*.mcgpu.xz).
 """
 from __future__ import annotations
 
@@ -23,39 +23,16 @@ geometry = pkg.geometry
 simulation = pkg.simulation
 materials = pkg.materials
 
-CACHE = Path(os.environ.get("MCGPU_TEST_CACHE", "/tmp/mcgpu_amd_test_cache"))
+CACHE = pkg.workloads.cache_dir()
 
 
 def material_files(raw_aluminium=False):
-    """The 22 material files in MC-GPU order.  The reference's aluminium table writes the integer columns ITL/ITU (and
-    KZCO/KSCO) as "1.0 4.0", on which the reference's unchecked `sscanf("%d %d")` leaves ITU uninitialised
-    (MC-GPU_v1.3.cu:2387-2392; DESIGN.md deviation 10).  So that the reference build and the engine read the SAME
-    numbers in the table-parity tests, the cases use a copy with those columns rewritten as integers;
-    `raw_aluminium=True` gives the file as shipped (test_formats_and_abi.py checks both parse to the same tables)."""
-    paths = materials.resolve_material_files([GOLDEN / "materials"], CACHE / "materials")
-    if raw_aluminium:
-        return paths
-    k = materials.material_number("aluminium") - 1
-    fixed = paths[k].with_name("aluminium__5_125kev.intcols.mcgpu")
-    if not fixed.is_file():
-        out, section = [], None
-        for line in paths[k].read_text().split("\n"):
-            if line.startswith("#"):
-                section = "rita" if "COMMON/CGRA/" in line else "shells" if "COMMON/CGCO/" in line else section
-            elif line.strip() and section in ("rita", "shells"):
-                t = line.split()
-                keep = 4 if section == "rita" else 3
-                line = " ".join(t[:keep] + [str(int(float(v))) for v in t[keep:]])
-            out.append(line)
-        tmp = fixed.with_name(fixed.name + f".tmp{os.getpid()}")
-        tmp.write_text("\n".join(out))
-        os.replace(tmp, fixed)
-    paths[k] = fixed
-    return paths
+    """The 22 material files in MC-GPU order (the package's assets: 4d-cbct-mc_amd/workloads.py)."""
+    return pkg.workloads.material_files(raw_aluminium)
 
 
 def spectrum_file():
-    return GOLDEN / "spectra" / "125kVp_0.89mmTi_varian_norm.spc"
+    return pkg.workloads.spectrum_file()
 
 
 # name -> (geometry factory, simulation kwargs).  Detector reduced 8x (231x96 px of 3.104 mm) so that

@@ -435,3 +435,35 @@ def test_environment_knobs_go_through_one_registry(engine, tmp_path):
     r = subprocess.run([str(exe), str(tmp_path / "missing.in")], capture_output=True, text=True, timeout=60, env=env)
     warn = [l for l in r.stdout.split("\n") if "MCGPU_THRESH_COMPTN" in l]
     assert len(warn) == 1 and "ignored" in warn[0] and not re.search("(?i)error", warn[0]) and "MCGPU_SWAP_BATCH" not in r.stdout
+
+
+def test_bench_builds_its_inputs_without_tests_and_oracle(tmp_path):
+    """the input builder of the product's benchmark lives in the package (4d-cbct-mc_amd/workloads.py, tables under
+    assets/); tests/ and oracle/ are checker-only imports of bench.py.  A tree without those two directories still imports bench.py,
+    resolves the 22 material tables and the spectrum, and writes a workload's geometry + input file."""
+    import subprocess
+    import sys
+    tree = tmp_path / "tree"
+    tree.mkdir()
+    import shutil
+    for entry in ROOT.iterdir():  # bench.py, bench_legs/ and __graft_entry__.py as copies: their ROOT is the tree without tests/ and oracle/
+        if entry.name in ("bench.py", "__graft_entry__.py"):
+            shutil.copy(entry, tree / entry.name)
+        elif entry.name == "bench_legs":
+            shutil.copytree(entry, tree / entry.name, ignore=shutil.ignore_patterns("__pycache__"))
+        elif entry.name in ("4d-cbct-mc_amd", "include"):
+            (tree / entry.name).symlink_to(entry)
+    code = ("import sys, bench\n"
+            "from pathlib import Path\n"
+            "pkg = bench.package()\n"
+            "assert not any(Path(p).name in ('tests', 'oracle') for p in sys.path), sys.path\n"
+            "m = pkg.workloads.material_files(); assert len(m) == 22 and all(f.is_file() and f.stat().st_size > 100000 for f in m)\n"
+            "assert pkg.workloads.spectrum_file().is_file()\n"
+            f"inp = bench.build_workload(Path({str(tmp_path / 'wl')!r}), 'catphan', 1000, 4, None, 32)\n"
+            "assert inp.is_file() and (inp.parent / 'geometry.vox').is_file()\n"
+            "print('ok', len(pkg.engine.knob_table()))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=tree, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MCGPU_TEST_CACHE=str(tmp_path / "cache"), PYTHONPATH=""))
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr[-2000:]
+    text = (tmp_path / "wl" / "input.in").read_text()
+    assert str(tmp_path / "cache" / "materials") in text and "geometry.vox" in text

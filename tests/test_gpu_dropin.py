@@ -188,10 +188,10 @@ def test_executable_falls_back_to_projection_sharding_without_an_exchange(engine
     r2 = subprocess.run([str(engine.EXE_PATH), str(b), "--devices", "0,0", "--stacks", "--crop", "128"], capture_output=True, text=True, timeout=600,
                         env=dict(os.environ, MCGPU_EXCHANGE_FAIL_PROBE="1"))
     assert r1.returncode == 0 and r2.returncode == 0, r1.stdout[-2000:] + r2.stdout[-2000:]
-    # the whole chain: exchange (probe fails) -> one RCCL reduction per projection (refused: RCCL wants one rank per GPU, and this
-    # box lists its only device twice) -> projection sharding
-    assert "trying one RCCL reduction per projection instead" in r2.stdout
-    assert r2.stdout.index("trying one RCCL reduction") < r2.stdout.index("every device simulates whole projections instead")
+    # AUTO: exchange (probe fails) -> projection sharding; the RCCL route is taken only when asked for (it has never run
+    # over more than one rank, and without peer access it would stage every tally through host memory)
+    assert "Tally exchange between the devices is not available: every device simulates whole projections instead" in r2.stdout
+    assert "RCCL reduction (uint64, sum)" not in r2.stdout and "listed twice" not in r2.stdout
     assert not re.search("(?i)error", r1.stdout) and not re.search("(?i)error", r2.stdout), r2.stdout[-1500:]
     for m in ("total", "unscattered", "scattered"):
         assert np.array_equal(engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / "two" / f"projections_{m}.mha")), m
@@ -215,7 +215,7 @@ def test_executable_rccl_reduction_route(engine, tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert not re.search("(?i)error", r.stdout), r.stdout[-1500:]
     assert "Detector tallies summed with one RCCL reduction (uint64, sum) per projection" in r1.stdout
-    assert "The RCCL reduction is not available either: every device simulates whole projections instead" in r2.stdout and "listed twice" in r2.stdout
+    assert "The RCCL reduction that was asked for is not available: every device simulates whole projections instead" in r2.stdout and "listed twice" in r2.stdout
     names = sorted(f.name for f in (tmp_path / "plain").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
     assert len(names) == 5
     data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]
