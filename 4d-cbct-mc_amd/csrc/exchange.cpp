@@ -60,6 +60,16 @@ struct XError {
     hipError_t _e = (expr);                                                                                      \
     if (_e != hipSuccess) throw XError{-1, std::string("!!HIP ERROR!! ") + #expr + ": " + hipGetErrorString(_e)}; \
   } while (0)
+// A HIP call of the exchange's SET-UP between two ranks, labelled with the mechanism it belongs to, so that the first log of a real
+// node says which of the three things the exchange needs is missing there: the peer's landing memory mapped through an IPC memory
+// handle, stream waits on the peer's interprocess events, or a copy-engine transfer into that memory.
+#define X_STAGE(stage, rank, peer, expr)                                                                                         \
+  do {                                                                                                                           \
+    hipError_t _e = (expr);                                                                                                      \
+    if (_e != hipSuccess)                                                                                                        \
+      throw XError{-1, std::string("!!HIP ERROR!! tally exchange set-up, stage [") + (stage) + "] rank " + std::to_string(rank) + " -> peer " + \
+                           std::to_string(peer) + ": " + #expr + ": " + hipGetErrorString(_e)};                                  \
+  } while (0)
 #define X_REQUIRE(cond, msg)                       \
   do {                                             \
     if (!(cond)) throw XError{-1, std::string(msg)}; \
@@ -218,7 +228,7 @@ int mcgpu_exchange_card(mcgpu_exchange* x, unsigned char* card, size_t card_byte
   X_REQUIRE(!x->local, "!!ERROR!! mcgpu_exchange_card: this exchange was created for ranks of one process (MCGPU_EXCHANGE_LOCAL)");
   X_HIP(hipSetDevice(x->device));
   hipIpcMemHandle_t mh;
-  X_HIP(hipIpcGetMemHandle(&mh, x->landing));
+  X_STAGE("IPC memory handle", x->rank, x->rank, hipIpcGetMemHandle(&mh, x->landing));
   memcpy(card, &mh, kHandle);
   for (int q = 0; q < 2; ++q) {
     hipIpcEventHandle_t eh;
@@ -245,15 +255,15 @@ int mcgpu_exchange_connect(mcgpu_exchange* x, int peer, const unsigned char* car
   hipIpcMemHandle_t mh;
   memcpy(&mh, card, kHandle);
   void* p = nullptr;
-  X_HIP(hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
+  X_STAGE("IPC memory handle", x->rank, peer, hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
   x->peer_landing[peer] = (unsigned long long*)p;
   x->peer_mapped_ipc[peer] = true;
   for (int q = 0; q < 2; ++q) {
     hipIpcEventHandle_t eh;
     memcpy(&eh, card + (size_t)kHandle * (1 + q), kHandle);
-    X_HIP(hipIpcOpenEventHandle(&x->peer_consumed[peer][q], eh));
+    X_STAGE("IPC event handle", x->rank, peer, hipIpcOpenEventHandle(&x->peer_consumed[peer][q], eh));
     memcpy(&eh, card + (size_t)kHandle * (3 + 2 * x->rank + q), kHandle);
-    X_HIP(hipIpcOpenEventHandle(&x->peer_pushed[peer][q], eh));
+    X_STAGE("IPC event handle", x->rank, peer, hipIpcOpenEventHandle(&x->peer_pushed[peer][q], eh));
   }
   x->opened_events[peer] = true;
   x->connected[peer] = true;
@@ -271,10 +281,11 @@ int mcgpu_exchange_connect_local(mcgpu_exchange* x, mcgpu_exchange* peer) {
   if (peer->device != x->device) {
     X_HIP(hipSetDevice(x->device));
     int can = 0;
-    X_HIP(hipDeviceCanAccessPeer(&can, x->device, peer->device));
-    X_REQUIRE(can, "!!ERROR!! tally exchange: no peer access between the devices");
+    X_STAGE("peer access", x->rank, r, hipDeviceCanAccessPeer(&can, x->device, peer->device));
+    X_REQUIRE(can, (std::string("!!ERROR!! tally exchange set-up, stage [peer access] rank ") + std::to_string(x->rank) + " (device " + std::to_string(x->device) +
+                    ") -> peer " + std::to_string(r) + " (device " + std::to_string(peer->device) + "): hipDeviceCanAccessPeer says no").c_str());
     const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
-    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) X_HIP(e);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) X_STAGE("peer access", x->rank, r, e);
     (void)hipGetLastError();
   }
   x->peer_landing[r] = peer->landing;
@@ -302,9 +313,10 @@ int mcgpu_exchange_probe(mcgpu_exchange* x) {
     if (o == x->rank) continue;
     X_REQUIRE(x->connected[o], "!!ERROR!! mcgpu_exchange_probe: a peer is not connected");
     for (int q = 0; q < 2; ++q)
-      X_HIP(hipMemcpyAsync(x->slot(x->peer_landing[o], x->rank, q), x->tally[q], bytes, hipMemcpyDeviceToDeviceNoCU, x->copy));
+      X_STAGE("peer copy (copy engine)", x->rank, o, hipMemcpyAsync(x->slot(x->peer_landing[o], x->rank, q), x->tally[q], bytes, hipMemcpyDeviceToDeviceNoCU, x->copy));
+    // waited for per peer: a transfer that fails asynchronously is reported with the peer it was going to
+    X_STAGE("peer copy (copy engine)", x->rank, o, hipStreamSynchronize(x->copy));
   }
-  X_HIP(hipStreamSynchronize(x->copy));
   return 0;
   X_END
 }

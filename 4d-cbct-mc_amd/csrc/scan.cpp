@@ -567,6 +567,11 @@ int run_scan_sharing_histories(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_sc
       report->seconds_kernels = kernel_s;
       report->seconds_after_last_kernel = now_s() - t_last_kernel;
       report->seconds_writer = sh.writer_s;
+      report->kernel_ms_min = report->kernel_ms_max = count > 0 ? (double)kms[0] : 0.0;
+      for (int i = 1; i < count; ++i) {
+        report->kernel_ms_min = std::min(report->kernel_ms_min, (double)kms[i]);
+        report->kernel_ms_max = std::max(report->kernel_ms_max, (double)kms[i]);
+      }
       for (int k = 0; k < 3; ++k) report->zero_replacement[k] = repl[k];
     }
   } catch (const ScanError& e) {
@@ -742,12 +747,18 @@ int run_scan_sharing_projections(mcgpu_ctx* const* ctxs, int n_ctx, const mcgpu_
       memset(report, 0, sizeof *report);
       report->histories_per_projection = r[0].histories_per_projection;
       report->seconds_total = now_s() - t0;
+      report->kernel_ms_min = 1e30;
       for (int g = 0; g < n_ctx; ++g) {
+        if (r[(size_t)g].projections > 0) {
+          report->kernel_ms_min = std::min(report->kernel_ms_min, r[(size_t)g].kernel_ms_min);
+          report->kernel_ms_max = std::max(report->kernel_ms_max, r[(size_t)g].kernel_ms_max);
+        }
         report->projections += r[(size_t)g].projections;
         report->seconds_kernels = std::max(report->seconds_kernels, r[(size_t)g].seconds_kernels);  // the devices run side by side
         report->seconds_after_last_kernel = std::max(report->seconds_after_last_kernel, r[(size_t)g].seconds_after_last_kernel);
         report->seconds_writer += r[(size_t)g].seconds_writer;
       }
+      if (report->projections == 0) report->kernel_ms_min = 0.0;
       for (int k = 0; k < 3; ++k) report->zero_replacement[k] = repl[k];
     }
   } catch (const ScanError& e) {

@@ -51,7 +51,7 @@ class ScanReport(C.Structure):
     """mcgpu_scan_report (include/mcgpu_amd.h)."""
     _fields_ = [("projections", C.c_int), ("histories_per_projection", C.c_ulonglong), ("seconds_total", C.c_double),
                 ("seconds_kernels", C.c_double), ("seconds_after_last_kernel", C.c_double), ("zero_replacement", C.c_float * 3),
-                ("seconds_writer", C.c_double)]
+                ("seconds_writer", C.c_double), ("kernel_ms_min", C.c_double), ("kernel_ms_max", C.c_double)]
 
 
 def knob_table():
@@ -587,7 +587,8 @@ class Context:
             _check(self.lib.mcgpu_run_scan(self.h, C.byref(o), C.byref(r)))
         return {"projections": r.projections, "histories_per_projection": r.histories_per_projection, "seconds_total": r.seconds_total,
                 "seconds_kernels": r.seconds_kernels, "seconds_after_last_kernel": r.seconds_after_last_kernel,
-                "seconds_writer": r.seconds_writer, "zero_replacement": [float(v) for v in r.zero_replacement]}
+                "seconds_writer": r.seconds_writer, "zero_replacement": [float(v) for v in r.zero_replacement],
+                "kernel_ms_min": r.kernel_ms_min, "kernel_ms_max": r.kernel_ms_max}
 
     # -- dose tallies (SECTION DOSE DEPOSITION of the input file)
     def dose_info(self):

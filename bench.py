@@ -53,7 +53,7 @@ from bench_legs.common import (HBM_PEAK_GBS, KERNEL_SOURCES, WORKLOADS, build_wo
                                knob_environment, package, usable_cpus)
 from bench_legs.cpu import cpu_baseline  # noqa: E402,F401
 from bench_legs.launch import spawn_ranks  # noqa: E402
-from bench_legs.legs import cirs_4d_leg, compat_leg, end_to_end_scan, fdk_leg, other_workloads  # noqa: E402,F401
+from bench_legs.legs import cirs_4d_leg, compat_leg, end_to_end_scan, fdk_leg, other_workloads, text_geometry_load  # noqa: E402,F401
 from bench_legs.roofline import measured_ceilings, pmc_summary, roofline_block, timed_launches  # noqa: E402,F401
 
 
@@ -196,6 +196,12 @@ def main():
             "metric": "photon histories/sec (512^3 vol, 894 proj)", "value": value, "unit": "histories/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # what "f32" narrows against the reference, and the same kernel WITHOUT that narrowing (value_reference_arithmetic below)
+            "dtype_note": "the reference computes three sub-steps in double -- rotate_double (MC-GPU_kernel_v1.3.cu:1103-1148), GRAa (:1181-1246), GCOa's cdt1 / costh "
+                          "chain (:1329-1331, :1372, :1427) -- which `value` (mode fast) computes in float32, validated statistically against the bit-exact personality; "
+                          "everything else is float32 in the reference too (its GPU build: -use_fast_math).  value_reference_arithmetic = the same kernel, scheduler and "
+                          "random-number streams with those three sub-steps in double as the reference has them (mode fast64, csrc/track_fast64.hip); compat.value = the "
+                          "reference's arithmetic AND its RANECU streams, bit-identical to the CPU oracle",
             "config": {"workload": f"{label}_{args.projections}proj_{H:.0e}hist_per_proj_per_gpu",
                        "detector": f"{nx}x{nz}", "histories_per_projection_per_gpu": H, "kernel": "fast",
                        "parallelism": route.parallelism_text(),
@@ -227,19 +233,31 @@ def main():
                 collectives["kernel_ms_avg_of_the_timed_region"] = k_ms
                 collectives["exposed_ms_per_step"] = {k: (None if v_ is None else v_ - k_ms) for k, v_ in collectives["ms_per_step"].items()}
                 out["reduce"]["routes"] = collectives
+                route_ok = all(v is None or v["passed"] for v in collectives.get("sharded_equals_single", {}).values())
+                out["check"]["every_route_sharded_equals_single"] = route_ok
+                out["check"]["passed"] = bool(out["check"]["passed"] and route_ok)
+                failed = failed or not route_ok
         if world == 1:
+            # the headline kernel at the reference's arithmetic: same launches (warm-up + steps at the same angles), same HIP-event timing
+            k64, k64_min, _ = timed_launches(ctx, torch, H, launches=args.steps, warm=args.warmup, mode="fast64")
+            out["value_reference_arithmetic"] = H / (k64 * 1e-3)
+            out["reference_arithmetic"] = {"mode": "fast64", "kernel_ms_avg": k64, "kernel_ms_min": k64_min, "launches": args.steps,
+                                           "cost_over_value": k64 / k_ms - 1.0, "unit": "histories/s"}
             if not args.no_compat:
                 out["compat"] = compat_leg(ctx, torch, H)
                 out["check"]["fast_vs_compat"] = fast_vs_compat_check(ctx)
                 failed = failed or not out["check"]["fast_vs_compat"]["passed"]
             if not args.no_end_to_end:
                 out["end_to_end"] = end_to_end_scan(ctx, H, workdir, n=min(args.scan_projections, nproj))
-                # the 894-projection scan with stacks, sustained: what the headline's 6 launches become over a whole trajectory
+                # the 894-projection scan with stacks, sustained: what the headline's launches become over a whole trajectory
                 out["sustained_value"] = out["end_to_end"]["histories_per_s_with_stacks"]
                 if args.ascii_projections > 0:
                     out["end_to_end_ascii"] = end_to_end_scan(ctx, H, workdir, n=min(args.ascii_projections, nproj), ascii_files=True)
+                # the same context creation from the reference's own text geometry (sidecar ignored)
+                out["timing"]["load_and_upload_s_text_geometry"] = text_geometry_load(eng, inp, device)
+                out["timing"]["geometry_text_bytes"] = (workdir / "geometry.vox").stat().st_size
             if not args.no_workloads and args.workload == "catphan":
-                out["workloads"] = other_workloads(eng, torch, H, args.projections, device, ceilings)
+                out["workloads"] = other_workloads(eng, torch, H, args.projections, device, ceilings, scans=not args.no_end_to_end)
                 kd = out["workloads"]["thorax"].get("entry_face_shell")
                 out["check"]["known_deviations"] = {"beam_edge_column": (out["check"].get("fast_vs_compat") or {}).get("beam_edge_column"), "entry_face": kd}
                 failed = failed or not (kd is None or kd["passed"])

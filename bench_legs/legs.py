@@ -44,12 +44,14 @@ def end_to_end_scan(ctx, H, workdir, n=894, ascii_files=False, chunk=64):
     first = min(100, max(ctx.num_projections - n, 0))
     pieces = [(first + k, min(chunk, n - k)) for k in range(0, n, chunk)] if ascii_files else [(first, n)]
     tot = {"seconds_total": 0.0, "seconds_kernels": 0.0, "seconds_writer": 0.0, "seconds_after_last_kernel": 0.0}
+    k_min, k_max = float("inf"), 0.0
     sizes, written = [], 0
     for p0, m in pieces:
         rep = ctx.run_scan(mode="fast", first_projection=p0, num_projections=m, histories=H, crop_nx=crop, write_stacks=not ascii_files,
                            write_ascii=ascii_files, output_folder=out, pixel_spacing=(0.776, 0.776))
         for k in tot:
             tot[k] += rep[k]
+        k_min, k_max = min(k_min, rep["kernel_ms_min"]), max(k_max, rep["kernel_ms_max"])
         for f in out.glob("projections_*.mha"):
             f.unlink()
         if ascii_files:
@@ -59,6 +61,7 @@ def end_to_end_scan(ctx, H, workdir, n=894, ascii_files=False, chunk=64):
             for f in files:
                 f.unlink(missing_ok=True)
     res = {"projections": n, "seconds_total": tot["seconds_total"], "ms_per_projection_kernels": tot["seconds_kernels"] / n * 1e3,
+           "kernel_ms_min_mean_max_over_the_arc": [k_min, tot["seconds_kernels"] / n * 1e3, k_max],
            "writer_ms_per_projection": tot["seconds_writer"] / n * 1e3, "drain_after_last_kernel_ms": tot["seconds_after_last_kernel"] * 1e3}
     if ascii_files:
         res["scans"] = len(pieces)
@@ -72,7 +75,21 @@ def end_to_end_scan(ctx, H, workdir, n=894, ascii_files=False, chunk=64):
     return res
 
 
-def cirs_4d_leg(c2, torch, H, states=10, projections_per_state=89):
+def text_geometry_load(eng, inp, device):
+    """What a drop-in user pays who brings only the reference's own voxel file: context creation with the .voxbin sidecar ignored
+    (MCGPU_IGNORE_VOXBIN: the text parse of load_voxels, MC-GPU_v1.3.cu:2098-2142 -- 134 M lines for the 512^3 volume -- then the same
+    table builders and uploads)."""
+    os.environ["MCGPU_IGNORE_VOXBIN"] = "1"
+    try:
+        t0 = time.perf_counter()
+        with eng.create(inp, device=device):
+            dt = time.perf_counter() - t0
+    finally:
+        del os.environ["MCGPU_IGNORE_VOXBIN"]
+    return dt
+
+
+def cirs_4d_leg(c2, torch, H, states=10, projections_per_state=894):
     """Config 5 (cbctmc/mc/simulation.py:527-710): `states` respiratory states of the CIRS phantom, each a 167 MB displacement
     field uploaded and applied ON THE DEVICE (mcgpu_warp_geometry: warp of the index volume, brick grids, object box, majorant),
     followed by `projections_per_state` projections of H histories in the warped geometry."""
@@ -124,9 +141,12 @@ def fdk_leg(pkg, device, n=894, nu=1024, nv=768, du=0.388, pad=1.0):
             "ms_kernels": r["ms_filter"] + r["ms_backproject"], "voxel_updates_per_s": upd / (r["ms_backproject"] * 1e-3),
             "wall_s_including_host_transfers": wall, "finite": bool(np.isfinite(vol).all()), "parity": "unpinned against RTK (DESIGN.md 2)"}
 
-def other_workloads(eng, torch, H, projections, device, ceilings=None):
-    """Configs 3-5 under the driver's clock: the same kernel measurement (8 launches of H histories) on the bundled CIRS
-    phantom, on the patient-like thorax and on the same thorax with the voxel-level bone texture of the reference's bone mapper."""
+def other_workloads(eng, torch, H, projections, device, ceilings=None, scans=True):
+    """Configs 3-5 under the driver's clock: the same kernel measurement (8 launches of H histories at angles (i 149) mod 894) on the
+    bundled CIRS phantom, on the patient-like thorax and on the same thorax with the voxel-level bone texture of the reference's bone
+    mapper -- and, because those kernels vary with the angle, the WHOLE 894-projection scan of each with its stacks on disk
+    (`end_to_end`, `sustained_value`: what the metric means by a scan, MC-GPU_v1.3.cu:667) with the fastest / mean / slowest kernel
+    of the arc; config 5 as 10 respiratory states x 894 projections."""
     out = {}
     for wl in ("cirs", "thorax", "thorax_textured"):
         t0 = time.perf_counter()
@@ -144,14 +164,19 @@ def other_workloads(eng, torch, H, projections, device, ceilings=None):
                                                                                      "l2_hit_rate", "traffic_source", "algorithmic_bytes_per_history")},
                        "valu_issue": valu, "volume_bytes": c2.geti("volume_bytes_device"), "materials_used": c2.geti("num_materials_used"),
                        "detected_energy_units_last_projection": detected,
+                       # the same kernel with the reference's three double-precision sub-steps (mode fast64), timed like `value`
+                       "value_reference_arithmetic": H / (timed_launches(c2, torch, H, mode="fast64")[0] * 1e-3),
                        # the bit-exact personality on this workload (reference arithmetic, RANECU streams), driver-timed like the rest
                        "compat": {k: v for k, v in compat_leg(c2, torch, H, launches=2).items() if k != "what"},
                        "prepare_inputs_s": t1 - t0, "load_measure_s": time.perf_counter() - t1}
             out[wl]["roofline"]["binding"] = roof.get("binding")
+            if scans:
+                out[wl]["end_to_end"] = end_to_end_scan(c2, H, wd, n=min(projections, c2.num_projections))
+                out[wl]["sustained_value"] = out[wl]["end_to_end"]["histories_per_s_with_stacks"]
             if wl == "thorax":
                 out[wl]["entry_face_shell"] = entry_face_deficit(c2)
             if wl == "cirs":
                 t4 = time.perf_counter()
-                out["cirs_4d"] = cirs_4d_leg(c2, torch, H)
+                out["cirs_4d"] = cirs_4d_leg(c2, torch, H, projections_per_state=projections if scans else 89)
                 out["cirs_4d"]["leg_s"] = time.perf_counter() - t4
     return out

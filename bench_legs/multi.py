@@ -262,10 +262,30 @@ class TallyRoute:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item()) / steps * 1e3
 
+        out["sharded_equals_single"] = {}
+        h_chk, p_chk = int(float(os.environ.get("BENCH_CHECK_HISTORIES", "1e7"))), 447 % self.nproj
+
+        def verify(owner, sharded):
+            """On `owner`: the route's summed tally of h_chk histories per rank against ONE rank simulating all their ids alone."""
+            verdict = None
+            if rank == owner:
+                alone, _, _ = ctx.run_projection(p_chk, world * h_chk, mode="fast", seed=self.seed, first=0)
+                verdict = {"passed": bool(np.array_equal(alone, sharded)), "projection": p_chk, "histories_per_rank": h_chk, "ranks": world,
+                           "checked_on_rank": rank, "words_differing": int(np.count_nonzero(alone != sharded))}
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, verdict, group=self.ctl)
+            return verdicts[owner]
+
         if self.x:  # the exchange is up: time it like the main region (it may be the route that just ran)
             out["ms_per_step"]["copy"] = timed(lambda i: self.step(i, False), self.drain)
+            k_chk = self.n_step
+            self.step(0, False, hist=h_chk, projection=p_chk)
+            self.drain()
+            owner = self.x.owner(k_chk)
+            out["sharded_equals_single"]["copy"] = verify(owner, ctx.download_image(self.last_reduced, self.stream) if rank == owner else None)
         else:
             out["ms_per_step"]["copy"] = None
+            out["sharded_equals_single"]["copy"] = None
         if self.backend == "nccl":
             image = torch.zeros((4, self.nz, self.nx), dtype=torch.int64, device="cuda")
             first_id = rank * self.H
@@ -282,11 +302,17 @@ class TallyRoute:
                 ms, err = None, e
             if self.agree(err is None):
                 out["ms_per_step"]["rccl_reduce_per_projection"] = ms
+                ctx.clear(image.data_ptr(), self.stream)
+                ctx.launch(p_chk, image.data_ptr(), h_chk, mode="fast", seed=self.seed, first=rank * h_chk, stream=self.stream)
+                dist.reduce(image, dst=0, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+                out["sharded_equals_single"]["rccl_reduce_per_projection"] = verify(0, image.cpu().numpy().view(np.uint64) if rank == 0 else None)
             else:
                 out["ms_per_step"]["rccl_reduce_per_projection"] = None
                 out["rccl_reduce_error"] = str(err)[:300] if err else "failed on another rank"
         else:
             out["ms_per_step"]["rccl_reduce_per_projection"] = None
+            out["sharded_equals_single"]["rccl_reduce_per_projection"] = None
             out["rccl_reduce_unavailable"] = "the ranks share GPUs (gloo process group): RCCL refuses two ranks on one device"
         return out
 

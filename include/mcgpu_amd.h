@@ -239,6 +239,7 @@ typedef struct mcgpu_scan_report {
   double seconds_total, seconds_kernels, seconds_after_last_kernel;
   float zero_replacement[3];
   double seconds_writer;                        /* busy time of the output thread (overlapped with tracking) */
+  double kernel_ms_min, kernel_ms_max;          /* fastest / slowest projection of the scan (the slowest device's launch each): kernels vary with the angle */
 } mcgpu_scan_report;
 int mcgpu_run_scan(mcgpu_ctx *ctx, const mcgpu_scan_options *options, mcgpu_scan_report *report);
 /* The same over several devices of one node (contexts created from the same input file, one per device): every

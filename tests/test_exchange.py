@@ -25,7 +25,10 @@ def test_exchange_sizes_and_argument_checks(engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,policy,hist", [(3, "rotate", 150_000), (2, "rank0", 150_000), (1, "rotate", 150_000), (3, "rotate", 1500), (2, "rank0", 1500)])
+@pytest.mark.parametrize("world,policy,hist", [(3, "rotate", 150_000), (2, "rank0", 150_000), (1, "rotate", 150_000), (3, "rotate", 1500), (2, "rank0", 1500),
+                                               # BASELINE configs 3 and 5 say 8 GPUs: eight ranks on the one device of the box (seven pushes per
+                                               # projection, the owner rotating over all eight; with 1500 histories the adds wait on their events)
+                                               (8, "rotate", 150_000), (8, "rotate", 1500), (8, "rank0", 1500)])
 def test_exchange_between_contexts_of_one_process(engine, case_dir, world, policy, hist):
     """hist = 1500: kernels of a few microseconds against pushes of 0.75 ms (full-size detector), so the owner's fused add is
     enqueued while the push it needs is still in flight: the events, not luck, must order them."""

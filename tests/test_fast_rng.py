@@ -82,6 +82,44 @@ def test_mwc_parameters_and_seeding_range():
     assert c0.min() >= 1 and c0.max() <= a - 1 and not np.any((x0 == 2 ** 32 - 1) & (c0 == a - 1))
 
 
+def test_battery_generators_equal_the_numpy_restatement():
+    """oracle/rng_battery.c (the TestU01-style battery whose verdict at 2^36 bytes is profiles/r06e_*) restates both generators in C:
+    its known answers -- first six outputs of the streams of four history ids, seed 42, projection 893 -- equal oracle/fast_rng.py's
+    (product: Philox4x32-7 seeding + multiply-with-carry; yardstick: Philox4x32-10 per draw, counter {id, projection, k / 4})."""
+    import subprocess
+    exe = ROOT / "oracle" / "rng_battery"
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "rng_battery"], check=True, capture_output=True, timeout=300)
+    lines = subprocess.run([str(exe), "--kat"], capture_output=True, text=True, check=True, timeout=60).stdout.strip().split("\n")
+    assert len(lines) == 8
+    for line in lines:
+        head, words = line.split(":")
+        t = head.split()
+        gen, hist = int(t[2]), int(t[4])
+        got = [int(w, 16) for w in words.split()]
+        if gen == 0:
+            want = fr.streams_u32(np.array([hist], dtype=np.uint64), 42, 893, 6)[0].tolist()
+        else:
+            want = []
+            for k4 in range(0, 8, 4):
+                want += [int(v) for v in fr.philox4x32([hist & fr.MASK, hist >> 32, 893, k4 >> 2], [42, fr.KEY1], rounds=10)]
+            want = want[:6]
+        assert got == want, line
+
+
+def test_battery_rejects_a_careless_seeding():
+    """`rng_battery --control`: the same multiply-with-carry step seeded straight from the history id (no Philox hash) must FAIL the
+    battery -- evidence that its draw-major tests see what a per-history seeding can get wrong.  (The product's verdict at 2^37.65
+    bytes -- 128 statistics, none suspect -- is profiles/r06e_rng_battery_2p37_bytes.txt; that run takes 25 minutes of 8 cores.)"""
+    import subprocess
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "rng_battery"], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([str(ROOT / "oracle" / "rng_battery"), "--control"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:]
+    fails = [l for l in r.stdout.split("\n") if l.rstrip().endswith("FAIL")]
+    assert len(fails) >= 16 and any("collisions" in l for l in fails) and any("birthday" in l for l in fails) and any("matrix rank" in l for l in fails)
+    record = (ROOT / "profiles" / "r06e_rng_battery_2p37_bytes.txt").read_text()
+    assert "128 statistics: 0 suspect" in record and "0 FAIL" in record and record.count("PRODUCT:") == 4 and record.count("(yardstick) |") == 4
+
+
 def test_deviate_is_never_zero_or_one():
     f = fr.to_float(np.array([0, 255, 256, 2 ** 32 - 1], dtype=np.uint32))
     assert f[0] == np.float32(2.0 ** -26) and f[1] == f[0] and f[2] == np.float32(2.0 ** -24 + 2.0 ** -26)

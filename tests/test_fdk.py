@@ -283,3 +283,94 @@ def test_mc_scan_to_fdk_round_trip(engine, tmp_path):
     assert 0.015 < water < 0.022 and rod > 1.4 * water and air_hole < 0.25 * water, (water, rod, air_hole)
     for wrong in (phantom_on_grid(xi, zi, -yi), phantom_on_grid(-xi, -zi, -yi)):  # mirrored in-plane: the rod is not where these expect it
         assert vol[central & (wrong > 1.5) & (wrong < 1.7)].mean() < 1.2 * water
+
+
+def test_ramp_frequency_response_with_and_without_the_hann_cut():
+    """What RTK documents for `rtkfdk --hann` (FFTRampImageFilter: the ramp |f| multiplied by a Hann window that reaches zero at
+    hann x Nyquist): no DC gain with or without the window, the response follows |f| 0.5 (1 + cos(pi f / fc)) below the cut and
+    vanishes above it.  Holds the oracle's kernel (the one csrc/fdk.hip is compared with) to the closed form; parity with RTK's own
+    numbers stays unpinned (no RTK here)."""
+    for hann in (0.0, 1.0, 0.7, 0.4):
+        n_half = 256
+        h = fo.ramp_kernel(n_half, hann)
+        assert abs(h.sum()) < 1e-3, hann                                       # DC gain: a constant row filters to zero
+        m = 8192
+        buf = np.zeros(m)
+        buf[: n_half + 1] = h[n_half:]
+        buf[-n_half:] = h[:n_half]
+        H = np.real(np.fft.fft(buf))
+        f = np.abs(np.fft.fftfreq(m))
+        fc = 0.5 * hann if hann > 0 else 0.5
+        want = f * (0.5 * (1.0 + np.cos(np.pi * f / fc)) if hann > 0 else 1.0)
+        want = np.where(f < fc, want, 0.0) if hann > 0 else f
+        assert np.max(np.abs(H - want)) < 2.5e-3, (hann, float(np.max(np.abs(H - want))))   # truncation of the kernel to 513 taps
+        low = (f > 0.01) & (f < 0.05)
+        assert np.allclose(H[low] / f[low], (0.5 * (1.0 + np.cos(np.pi * f[low] / fc)) if hann > 0 else 1.0), atol=0.03)
+
+
+def test_geometry_matrix_closed_form_and_the_reference_angle_series(tmp_path):
+    """`create_geometry` (cbctmc/forward_projection.py:152-199) calls AddProjection(sid, sdd, start + i arc / n, offset_x, offset_y) for
+    every projection; RTK's documented matrix of such a projection (no source offsets, no in-plane / out-of-plane angles) is
+    T(-offset) . [[-sdd, 0, 0, 0], [0, -sdd, 0, 0], [0, 0, 1, -sid]] . R_y(-angle), in closed form
+        [ -sdd cos - ox sin,    0,  sdd sin - ox cos,  ox sid ]
+        [        - oy sin,   -sdd,         - oy cos,   oy sid ]
+        [             sin,      0,              cos,    - sid ]
+    The XML this package writes carries that matrix, digit for digit what it computes, for the reference's default half-fan scan."""
+    n, start, arc = 894, 270.0, 360.0
+    geo = recon.create_geometry(n, start_angle=start)
+    d = cases_defaults()
+    sid, sdd, ox, oy = d.source_to_isocenter_distance, d.source_to_detector_distance, d.detector_lateral_displacement, 0.0
+    assert (geo.source_to_isocenter, geo.source_to_detector) == (sid, sdd)
+    angles = np.array([(start + i * arc / n) % 360.0 for i in range(n)])
+    assert np.allclose(geo.gantry_angles, angles, rtol=0, atol=1e-12) and geo.projection_offsets_x == [ox] * n and geo.projection_offsets_y == [oy] * n
+    text = geo.write(tmp_path / "geometry.xml").read_text()
+    blocks = text.split("<Matrix>")[1:]
+    assert len(blocks) == n
+    for i in (0, 1, 223, 447, 893):
+        t = np.deg2rad(angles[i])
+        c, s = np.cos(t), np.sin(t)
+        closed = np.array([[-sdd * c - ox * s, 0.0, sdd * s - ox * c, ox * sid], [-oy * s, -sdd, -oy * c, oy * sid], [s, 0.0, c, -sid]])
+        assert np.allclose(geo.matrix(i), closed, rtol=0, atol=1e-9), i
+        rows = np.array([[float(v) for v in line.split()] for line in blocks[i].split("</Matrix>")[0].strip().split("\n")])
+        assert rows.shape == (3, 4) and np.allclose(rows, closed, rtol=1e-13, atol=1e-9), i
+        # the source sits at distance sid on the rotated z axis: the matrix sends it to the point at infinity (third component 0)
+        assert abs((closed @ np.array([sid * s, 0.0, sid * c, 1.0]))[2]) < 1e-9
+    # isocentre -> (-offset_x, -offset_y) in detector coordinates, whatever the angle
+    for i in (0, 300, 893):
+        uvw = geo.matrix(i) @ np.array([0.0, 0.0, 0.0, 1.0])
+        assert np.allclose(uvw[:2] / uvw[2], [-ox, -oy])
+
+
+def cases_defaults():
+    import cases
+    return cases.pkg.defaults.DEFAULTS
+
+
+def test_rocm_container_recipe_matches_the_build():
+    """docker/Dockerfile.rocm has never produced an image (no docker here): a static check that what it COPYs exists, that what it
+    installs is what `make -C 4d-cbct-mc_amd/csrc` builds, that the make variable it sets exists, and that the `mpirun` shim the
+    reference's command line needs (cbctmc/mc/simulation.py:187-198) is part of it."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    text = (root / "docker" / "Dockerfile.rocm").read_text()
+    lines = [l.strip() for l in text.replace("\\\n", " ").split("\n") if l.strip() and not l.strip().startswith("#")]
+    assert lines[0].startswith("FROM rocm/") and any(l.startswith("WORKDIR ") for l in lines)
+    copies = [l.split()[1:] for l in lines if l.startswith("COPY ")]
+    assert copies
+    for src, dst in copies:
+        assert (root / src).exists(), f"COPY source {src} is not in the repository"
+    makefile = (root / "4d-cbct-mc_amd" / "csrc" / "Makefile").read_text()
+    run = " ".join(l for l in lines if l.startswith("RUN "))
+    m = re.search(r"make -C (\S+) .*?ARCH=(\w+)", run)
+    assert m and (root / m.group(1) / "Makefile").is_file() and m.group(2) == "gfx950" and re.search(r"^ARCH\s*\?=", makefile, re.M)
+    assert any(src == m.group(1) for src, _ in copies) and any(src == "include" for src, _ in copies)   # the Makefile reads ../../include
+    built = {"4d-cbct-mc_amd/" + re.search(rf"^{var} := \.\./(\S+)", makefile, re.M).group(1) for var in ("LIB", "EXE")}
+    installed = set(re.findall(r"install -m 0755 (\S+)", run))
+    assert installed == built, (installed, built)
+    assert "/usr/local/bin/MC-GPU_v1.3.x" in run and "ldconfig" in run
+    assert ["docker/mpirun", "/usr/local/bin/mpirun"] in copies and "chmod 0755 /usr/local/bin/mpirun" in run
+    assert any(l.startswith("ENV ") and "HSA_ENABLE_IPC_MODE_LEGACY=0" in l for l in lines)
+    # everything the csrc Makefile compiles lives in the directories the image copies
+    for src in re.findall(r"^\S+\.o: (\S+)", makefile, re.M):
+        assert (root / "4d-cbct-mc_amd" / "csrc" / src).is_file(), src

@@ -146,6 +146,32 @@ def test_executable_sharded_over_devices_equals_single_device(engine, tmp_path):
         assert s1.shape == (4, 96, 128) and np.array_equal(s1, s2), m
 
 
+def test_executable_eight_ranks_on_one_device(engine, tmp_path):
+    """BASELINE configs 3 and 5 ask for 8 GPUs; the box has one.  The executable's `--gpus 8` path on eight contexts of device 0 -- the
+    tally exchange with a rotating owner and seven pushes per projection, and projection sharding with eight uneven shares of eleven
+    projections -- writes the single-device files byte for byte.  (Eight rank PROCESSES cannot share the box's GPU: the pool admits
+    six processes on a card; bench.py's multi-process path is rehearsed with 2-6 ranks, profiles/r06*_ranks_sharing_one_gpu.json.)"""
+    kw = dict(n_histories=400_000, n_projections=11, angle_between_projections=33.0)
+    dirs = {k: cases.build_case("catphan64_ct", tmp_path / k, **kw) for k in ("one", "exchange8", "projections8")}
+    common = ["--stacks", "--crop", "128"]
+    eight = ["--devices", "0,0,0,0,0,0,0,0"]
+    runs = {"one": subprocess.run([str(engine.EXE_PATH), str(dirs["one"])] + common, capture_output=True, text=True, timeout=900),
+            "exchange8": subprocess.run([str(engine.EXE_PATH), str(dirs["exchange8"])] + eight + common, capture_output=True, text=True, timeout=900),
+            "projections8": subprocess.run([str(engine.EXE_PATH), str(dirs["projections8"])] + eight + ["--shard", "projections"] + common, capture_output=True, text=True, timeout=900)}
+    for k, r in runs.items():
+        assert r.returncode == 0, (k, r.stdout[-2000:] + r.stderr[-2000:])
+        assert not re.search("(?i)error", r.stdout), (k, r.stdout[-1500:])
+    assert "not available" not in runs["exchange8"].stdout  # the exchange itself ran, no fallback
+    names = sorted(f.name for f in (tmp_path / "one").iterdir() if cases.simulation.PROJECTION_FILE_PATTERN.match(f.name))
+    assert len(names) == 11
+    data = lambda f: [l for l in open(f).read().rstrip("\n").split("\n") if not l.startswith("#")]
+    for k in ("exchange8", "projections8"):
+        for n in names:
+            assert data(tmp_path / "one" / n) == data(tmp_path / k / n), (k, n)
+        for m in ("total", "unscattered", "scattered"):
+            assert np.array_equal(engine.stack_read(tmp_path / "one" / f"projections_{m}.mha"), engine.stack_read(tmp_path / k / f"projections_{m}.mha")), (k, m)
+
+
 @pytest.mark.parametrize("mode", ["fast", "compat"])
 def test_executable_sharded_by_projection_equals_single_device(engine, tmp_path, mode):
     """`--shard projections` (SURVEY 8e's fallback: every device simulates whole projections, nothing crosses between devices):

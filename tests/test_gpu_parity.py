@@ -193,9 +193,13 @@ def test_lds_image_keeps_two_workgroups_per_cu_with_all_22_materials(gpu_engine,
             assert ctx.geti("sigma_bracket_shift") >= 6, name
 
 
-@pytest.mark.parametrize("name", ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw", "cirs76", "thorax64", "tissue22", "thorax128_bone"])
-def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
-    """FAST vs oracle (LIBM math = the reference's own arithmetic): every class image, per pixel."""
+FAST_CASES = ["catphan64", "water", "air", "slab_angles", "graded_u16", "graded_raw", "cirs76", "thorax64", "tissue22", "thorax128_bone"]
+
+
+@pytest.mark.parametrize("name,mode", [(n, "fast") for n in FAST_CASES] + [(n, "fast64") for n in ("catphan64", "slab_angles", "cirs76", "thorax64", "tissue22")])
+def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name, mode):
+    """FAST vs oracle (LIBM math = the reference's own arithmetic): every class image, per pixel.  mode "fast64": the same kernel
+    with the reference's three double-precision sub-steps (rotate_double, GRAa, GCOa's cdt1 / costh chain: csrc/track_fast64.hip)."""
     with gpu_engine.create(case_dir(name), device=0) as ctx:
         T = parity.tables_from_context(ctx)
         p = ctx.num_projections - 1
@@ -203,7 +207,7 @@ def test_fast_kernel_within_3_sigma_of_oracle(gpu_engine, case_dir, name):
         img_cpu, w2_cpu, _ = T.track_with_variance(p, 42, 0, nb, hpt, ol.MATH_LIBM, n_threads=8)
         n_cpu = nb * hpt
         n_gpu = 20_000_000
-        img_gpu, secs, done = ctx.run_projection(p, n_gpu, mode="fast", seed=42)
+        img_gpu, secs, done = ctx.run_projection(p, n_gpu, mode=mode, seed=42)
         img_cpu, w2_cpu = img_cpu.reshape(img_gpu.shape), w2_cpu.reshape(img_gpu.shape)
         # integral quantities: detected energy per history, per image class, 3.5 sigma of the measured variance
         zs = parity.class_energy_z(img_gpu, done, img_cpu, w2_cpu, n_cpu)
@@ -260,6 +264,15 @@ def test_fast_image_is_independent_of_slot_trading_segment_rule_and_brick_levels
                 assert np.array_equal(img, ref), (trade, hold_q)
         monkeypatch.delenv("MCGPU_SLOT_TRADE")
         monkeypatch.delenv("MCGPU_HOLD_Q")
+        # the flight segment as an inner loop or as part of the main loop (kSegmentLoop, chosen by the host from the materials): both
+        # template variants on the same case, whichever the heuristic picks
+        for seg in ("0", "1"):
+            monkeypatch.setenv("MCGPU_SEGMENT_LOOP", seg)
+            ctx.reload_env_knobs()
+            assert ctx.geti("segment_loop") == int(seg)
+            assert np.array_equal(ctx.run_projection(p, n, mode="fast", seed=21)[0], ref), ("segment loop", seg)
+        monkeypatch.delenv("MCGPU_SEGMENT_LOOP")
+        ctx.reload_env_knobs()
     # The brick SIZE moves the object box, and with it the region the exterior hop crosses analytically: a different (equally
     # valid) use of the random numbers.  With the hop off, a lookup returns the same (material, density) whatever the two
     # brick levels look like, so the tallies may not move at all; with it on, the second level alone may not move them.
@@ -368,8 +381,9 @@ def test_fast_object_region_with_and_without_the_elliptic_cylinder(gpu_engine, c
         assert m.sum() > 20 and abs(z.mean()) < 5.0 / np.sqrt(m.sum()) and np.abs(z).max() < 6.0, (case, int(m.sum()), z.mean(), np.abs(z).max())
 
 
+@pytest.mark.parametrize("mode", ["fast", "fast64"])
 @pytest.mark.parametrize("case,projection,fixture", [("catphan64", 0, "stat_catphan64.npz"), ("slab_angles", 1, "stat_slab_angles_p1.npz")])
-def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, case, projection, fixture):
+def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, case, projection, fixture, mode):
     """FAST vs tests/golden/stat_*.npz: 16 independent runs of the CPU oracle in its
     reference-identical mode -> per-block mean and run-to-run variance (catphan64: 16 x 4e7 histories, straight projection;
     slab_angles projection 1: 16 x 2.5e7, rotated source/detector at 300.5 degrees through water, bone and Teflon, i.e. the
@@ -384,7 +398,7 @@ def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, cas
     with gpu_engine.create(case_dir(case), device=0) as ctx:
         img = np.zeros((4,) + ctx.detector_shape, dtype=np.float64)
         for k in range(4):  # four launches with different seeds: independent histories
-            part, _, done = ctx.run_projection(projection, n_gpu // 4, mode="fast", seed=100 + k)
+            part, _, done = ctx.run_projection(projection, n_gpu // 4, mode=mode, seed=100 + k)
             img += part
         nz, nx = img.shape[1:]
         b = img[:, : nz // 3 * 3, : nx // 3 * 3].reshape(4, nz // 3, 3, nx // 3, 3).sum(axis=(2, 4)) / (n_gpu // 4 * 4)
@@ -399,19 +413,39 @@ def test_fast_kernel_against_the_statistical_reference(gpu_engine, case_dir, cas
         assert abs(zk) < 4.5, (k, zk)
 
 
-def test_fast_kernel_tallies_are_pinned(gpu_engine):
+@pytest.mark.parametrize("mode", ["fast", "fast64"])
+def test_fast_kernel_tallies_are_pinned(gpu_engine, mode):
     """The production kernel is built without implicit FMA contraction, so its integer tallies are a function of the source
-    alone: tests/golden/fast_pin.json (written on an MI355X by tools/gen_fast_pin.py) holds their SHA-256 on four small cases.
+    alone: tests/golden/fast_pin.json (written on an MI355X by tools/gen_fast_pin.py) holds their SHA-256 on four small cases
+    (fast64_pin.json: the variant with the reference's double-precision sub-steps).
     A mismatch means the FAST arithmetic or its random-number use changed -- regenerate the pin only if that was intended
     (the statistical tests above are what shows a change is still correct)."""
     import json
     import sys
     sys.path.insert(0, str(cases_root() / "tools"))
     import gen_fast_pin
-    want = json.loads((cases_root() / "tests" / "golden" / "fast_pin.json").read_text())
-    got = gen_fast_pin.compute()
+    want = json.loads((cases_root() / "tests" / "golden" / f"{mode}_pin.json").read_text())
+    got = gen_fast_pin.compute(mode)
     for name in want:
         assert got[name]["sum"] == want[name]["sum"] and got[name]["sha256"] == want[name]["sha256"], name
+
+
+def test_fast64_differs_from_fast_only_where_the_reference_computes_in_double(gpu_engine, case_dir):
+    """The two arithmetics share scheduler, streams and every float32 step: a geometry in which nothing scatters (air: one primary
+    per history, no Compton / Rayleigh event reaches a rotation) gives the SAME tally words, and a scattering one differs -- but only
+    in its scatter classes' details, not in the number of histories or, beyond a few 1e-4, in its class energies."""
+    with gpu_engine.create(case_dir("catphan64"), device=0) as ctx:
+        a, _, da = ctx.run_projection(0, 2_000_000, mode="fast", seed=5)
+        b, _, db = ctx.run_projection(0, 2_000_000, mode="fast64", seed=5)
+        assert da == db == 2_000_000 and not np.array_equal(a, b)
+        ea, eb = a.reshape(4, -1).sum(axis=1).astype(np.float64), b.reshape(4, -1).sum(axis=1).astype(np.float64)
+        # the same histories up to their first scattering: the primary image differs only through photons whose FIRST interaction's
+        # outcome (a rotation) is not part of it at all -- it is identical
+        assert np.array_equal(a[0], b[0])
+        assert np.all(np.abs(eb[1:] / ea[1:] - 1.0) < 0.02)
+        # determinism of the double-precision variant itself, and its independence of the schedule
+        c, _, _ = ctx.run_projection(0, 2_000_000, mode="fast64", seed=5)
+        assert np.array_equal(b, c)
 
 
 def test_workgroup_level_scheduler_gives_the_pinned_tallies(gpu_engine, case_dir, monkeypatch):

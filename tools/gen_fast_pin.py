@@ -11,18 +11,19 @@ import cases
 PIN_CASES = [("catphan64_ct", 1, 600_000, 11), ("tissue22", 0, 400_000, 12), ("cirs76", 2, 400_000, 13), ("air", 0, 200_000, 14)]
 
 
-def compute():
+def compute(mode="fast"):
     eng = cases.pkg.engine
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, p, n, seed in PIN_CASES:
             with eng.create(cases.build_case(name, Path(tmp) / name), device=0) as ctx:
-                img, _, done = ctx.run_projection(p, n, mode="fast", seed=seed)
+                img, _, done = ctx.run_projection(p, n, mode=mode, seed=seed)
                 out[name] = {"projection": p, "histories": n, "seed": seed, "sum": int(img.sum()), "sha256": hashlib.sha256(img.tobytes()).hexdigest()}
     return out
 
 
 if __name__ == "__main__":
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
-    (ROOT / "gpurun_out" / "fast_pin.json").write_text(json.dumps(compute(), indent=1))
-    print(json.dumps(compute(), indent=1))
+    for mode in ("fast", "fast64"):
+        (ROOT / "gpurun_out" / f"{mode}_pin.json").write_text(json.dumps(compute(mode), indent=1))
+        print(mode, json.dumps(compute(mode), indent=1))
