@@ -31,6 +31,7 @@ hipError_t launch_track_fast(const TrackArgs& args, int blocks, hipStream_t stre
 int occupancy_track_fast(const TrackArgs& args);
 hipError_t launch_track_fast64(const TrackArgs& args, int blocks, hipStream_t stream);  // MCGPU_MODE_FAST_F64 (track_fast64.hip)
 int occupancy_track_fast64(const TrackArgs& args);
+hipError_t launch_kat_fast64(int n, const unsigned int* u, const double* a, const double* b, const double* c, const float* dir, double* out, hipStream_t stream);
 #if defined(MC_WITH_STATS) && MC_WITH_STATS
 hipError_t launch_track_stats(const TrackArgs& args, int blocks, hipStream_t stream);  // diagnostic library only (track_stats.o)
 #endif

@@ -76,6 +76,30 @@ int mcgpu_kat_math(mcgpu_ctx* ctx, int n, const double* x, double* out_log, doub
   ABI_END
 }
 
+int mcgpu_kat_fast64(mcgpu_ctx* ctx, int n, const uint32_t* u, const double* a, const double* b, const double* c, const float* dir3, double* out8) {
+  ABI_BEGIN
+  require(ctx && ctx->has_device && u && a && b && c && dir3 && out8 && n > 0, -1, "!!ERROR!! mcgpu_kat_fast64: bad argument");
+  HIP_TRY(hipSetDevice(ctx->dev.device_id));
+  unsigned char* d = nullptr;
+  const size_t n8 = (size_t)n * 8, n4 = (size_t)n * 4;
+  HIP_TRY(hipMalloc((void**)&d, 11 * n8 + n4 + 3 * n4));  // out (8 n doubles) | a | b | c | u | dir
+  double* d_out = (double*)d;
+  double *d_a = d_out + 8 * (size_t)n, *d_b = d_a + n, *d_c = d_b + n;
+  unsigned int* d_u = (unsigned int*)(d_c + n);
+  float* d_dir = (float*)(d_u + n);
+  hipError_t e = hipMemcpy(d_a, a, n8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_b, b, n8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_c, c, n8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_u, u, n4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_dir, dir3, 3 * n4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_kat_fast64(n, d_u, d_a, d_b, d_c, d_dir, d_out, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out8, d_out, 8 * n8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return 0;
+  ABI_END
+}
+
 int mcgpu_kat_f32(mcgpu_ctx* ctx, int op, int n, const float* a, const float* b, float* inout) {
   ABI_BEGIN
   require(ctx && ctx->has_device && a && b && inout && n > 0 && op >= 0 && op <= 4, -1, "!!ERROR!! mcgpu_kat_f32: bad argument");

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mcgpu_finalize_projection", "mcgpu_finalize_projection_host", "mcgpu_stack_create", "mcgpu_stack_append", "mcgpu_stack_write_slice", "mcgpu_stack_finish",
     "mcgpu_stack_read", "mcgpu_normalize_stack", "mcgpu_run_scan", "mcgpu_run_scan_multi", "mcgpu_set_projection_angles", "mcgpu_set_geometry_arrays",
     "mcgpu_warp_volume", "mcgpu_warp_geometry",
-    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_microbench", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_kat_tile_records", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
+    "mcgpu_write_voxel_file", "mcgpu_write_voxel_binary", "mcgpu_kat_rng", "mcgpu_kat_rng_streams", "mcgpu_microbench", "mcgpu_kat_math", "mcgpu_kat_expf", "mcgpu_kat_f32", "mcgpu_kat_fast64", "mcgpu_kat_tile_records", "mcgpu_fdk_reconstruct", "mcgpu_set_fast_schedule", "mcgpu_reload_env_knobs",
     "mcgpu_exchange_shared_bytes", "mcgpu_exchange_card_bytes", "mcgpu_exchange_create", "mcgpu_exchange_card", "mcgpu_exchange_connect",
     "mcgpu_exchange_connect_local", "mcgpu_exchange_probe", "mcgpu_exchange_owner", "mcgpu_exchange_begin", "mcgpu_exchange_submit", "mcgpu_exchange_collect",
     "mcgpu_exchange_stats", "mcgpu_exchange_destroy", "mcgpu_copy_to_host",
@@ -154,6 +154,7 @@ def load_library(path: Optional[os.PathLike] = None):
     lib.mcgpu_kat_math.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     lib.mcgpu_kat_expf.argtypes = [vp, ci, vp, vp]
     lib.mcgpu_kat_f32.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.mcgpu_kat_fast64.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.mcgpu_kat_tile_records.argtypes = [ci, vp, vp]
     if path is None:
         _lib = lib
@@ -663,6 +664,16 @@ class Context:
         outs = [np.zeros_like(x) for _ in range(4)]
         _check(self.lib.mcgpu_kat_math(self.h, x.size, x.ctypes.data, *[o.ctypes.data for o in outs]))
         return outs
+
+    def kat_fast64(self, u, a, b, c, directions):
+        """float64[n, 8] of mcgpu_kat_fast64: sin, cos, 1/sqrt(a), sqrt(a/b), cdt1, rotated direction (3)."""
+        u = np.ascontiguousarray(u, dtype=np.uint32)
+        a, b, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, c))
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert u.size == a.size == b.size == c.size == d.shape[0]
+        out = np.zeros((u.size, 8), dtype=np.float64)
+        _check(self.lib.mcgpu_kat_fast64(self.h, u.size, u.ctypes.data, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, out.ctypes.data))
+        return out
 
     def kat_f32(self, op: int, a, b=None, c=None):
         """Float operations of the COMPAT kernel (include/mcgpu_amd.h: mcgpu_kat_f32)."""

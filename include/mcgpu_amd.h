@@ -358,6 +358,10 @@ int mcgpu_kat_math(mcgpu_ctx *ctx, int n, const double *x, double *out_log, doub
 int mcgpu_kat_expf(mcgpu_ctx *ctx, int n, const float *x, float *out_exp);
 /* float operations of the COMPAT kernel: op 0 its lean square root, 1 sqrtf, 2 its lean quotient a/b, 3 a/b, 4 shell_pz(a, b, inout) */
 int mcgpu_kat_f32(mcgpu_ctx *ctx, int op, int n, const float *a, const float *b, float *inout);
+/* Double-precision helpers of MCGPU_MODE_FAST_F64 (csrc/track_fast64.hip), item i -> out8[8 i ..]: sin and cos of
+ * 2 pi (u[i] + 1/2) 2^-32; 1 / sqrt(a[i]); sqrt(a[i] / b[i]); cdt1 of MC-GPU_kernel_v1.3.cu:1329 at tau = (float)a[i], E = (float)b[i] 1e5;
+ * the direction dir3[3 i ..] rotated by polar cosine c[i] and the azimuth of u[i] (rotate_double, :1103-1148). */
+int mcgpu_kat_fast64(mcgpu_ctx *ctx, int n, const uint32_t *u, const double *a, const double *b, const double *c, const float *dir3, double *out8);
 /* The 16-byte record of a 4x4x4 tile of a u8-palette volume as the host and the device build it (csrc/device_model.hpp:
  * encode_tile_record; no reference counterpart -- the reference gathers the voxel itself, MC-GPU_kernel_v1.3.cu:262-266).  Host code
  * only, no context: indices[t * 64 + v] = palette index of voxel v = (iz & 3) 16 + (iy & 3) 4 + (ix & 3) of tile t, negative = padding

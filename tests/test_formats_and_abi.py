@@ -467,3 +467,23 @@ def test_bench_builds_its_inputs_without_tests_and_oracle(tmp_path):
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr[-2000:]
     text = (tmp_path / "wl" / "input.in").read_text()
     assert str(tmp_path / "cache" / "materials") in text and "geometry.vox" in text
+
+
+def test_double_constants_of_the_fast64_kernel_are_what_their_comments_say():
+    """csrc/track_common.inc spells its double constants as two 32-bit scalar words (`sconst(lo, hi) /* value */`: v_fma_f64 takes no
+    64-bit literal and the compiler would otherwise hoist them into vector registers): the words are the IEEE-754 bits of the value."""
+    import struct
+    text = (ROOT / "4d-cbct-mc_amd" / "csrc" / "track_common.inc").read_text()
+    found = re.findall(r"sconst\(0x([0-9a-f]{8})u, 0x([0-9a-f]{8})u\) /\* ([^*]+?) \*/", text)
+    assert len(found) >= 15
+    for lo, hi, value in found:
+        v = {"2 pi 2^-32": 6.28318530717958647693 * 2.0 ** -32}.get(value.strip())
+        v = float(value) if v is None else v
+        assert struct.unpack("<II", struct.pack("<d", v)) == (int(lo, 16), int(hi, 16)), value
+    # ... and the polynomial coefficients of sincos_turn are the Taylor ones their trailing comments name (a 1/13! copied from a
+    # minimax table once cost 7e-14 of accuracy at a quarter-turn border: found by the device known-answer test, kept out by this one)
+    import math
+    taylor = re.findall(r"/\* (-?[0-9.e+-]+) \*/\)?;\s+// (-?)1/(\d+)!", text)
+    assert len(taylor) == 14
+    for value, sign, k in taylor:
+        assert float(value) == (-1.0 if sign else 1.0) / math.factorial(int(k)), (value, k)

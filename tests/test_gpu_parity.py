@@ -518,3 +518,61 @@ def test_fast_kernel_small_and_ragged_history_counts(gpu_engine, case_dir):
         big, _, _ = ctx.run_projection(0, 3_000_000, mode="fast", seed=3)
         again, _, _ = ctx.run_projection(0, 1000, mode="fast", seed=3)
         assert np.array_equal(again, whole) and big.sum() > whole.sum()
+
+
+def test_fast64_double_precision_helpers_against_numpy(gpu_engine, case_dir):
+    """csrc/track_fast64.hip's own arithmetic, held to double-precision numpy directly (the statistical tests cannot see an azimuth that is
+    off by a quarter turn: scattering is symmetric about the photon's direction): sincos_turn over all four quadrants and their
+    borders, rsqrt_d / sqrt_ratio_d / the refined quotient of compton_cdt1 to a few ulp of DOUBLE, and rotate_double
+    (MC-GPU_kernel_v1.3.cu:1103-1148) restated in numpy float64 to one ulp of the float32 result."""
+    rng = np.random.default_rng(3)
+    n = 20000
+    u = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    u[:12] = [0, 1, 2 ** 29 - 1, 2 ** 29, 2 ** 30 - 1, 2 ** 30, 2 ** 31 - 1, 2 ** 31, 3 * 2 ** 30, 2 ** 32 - 2 ** 29, 2 ** 32 - 2 ** 29 - 1, 2 ** 32 - 1]
+    a = np.concatenate([10.0 ** rng.uniform(-12, 6, n - 4), [1.0, 0.25, 1.0 - 2.0 ** -30, 1.0 + 2.0 ** -29]])
+    b = 10.0 ** rng.uniform(-20, 3, n)
+    costh = np.concatenate([rng.uniform(-1, 1, n - 4), [1.0, -1.0, 1.0 - 1e-12, 0.0]])
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:40, :2] = 0.0; d[:40, 2] = np.where(np.arange(40) % 2 == 0, 1.0, -1.0)   # along +-z: the untilted branch (DXY <= 1e-28)
+    d = d.astype(np.float32)
+    # compton_cdt1 is fed tau in (0, 1] and E in eV: a -> tau, b -> E / 1e5
+    tau = rng.uniform(0.55, 1.0, n).astype(np.float32)
+    e5 = rng.uniform(0.1, 1.25, n).astype(np.float32)
+    with gpu_engine.create(case_dir("water"), device=0) as ctx:
+        out = ctx.kat_fast64(u, a, b, costh, d)
+        out_c = ctx.kat_fast64(u, tau.astype(np.float64), e5.astype(np.float64), costh, d)
+    phi = 2.0 * np.pi * ((u.astype(np.float64) + 0.5) * 2.0 ** -32)
+    # argument reduction is exact on the device (integer quarter turns); numpy's sin(2 pi x) carries the rounding of 2 pi x: 2e-16 x 6.3
+    assert np.max(np.abs(out[:, 0] - np.sin(phi))) < 2e-15 and np.max(np.abs(out[:, 1] - np.cos(phi))) < 2e-15
+    assert np.max(np.abs(out[:, 0] ** 2 + out[:, 1] ** 2 - 1.0)) < 5e-16
+    assert np.max(np.abs(out[:, 2] * np.sqrt(a) - 1.0)) < 5e-16                           # 1 / sqrt(a)
+    assert np.max(np.abs(out[:, 3] / np.sqrt(a / b) - 1.0)) < 1e-15                       # sqrt(a / b)
+    ref = (1.0 - tau).astype(np.float64) / (tau.astype(np.float64) * (e5 * np.float32(1.0e5)).astype(np.float64) * 1.956951306108245e-6)
+    ref = np.where(ref > 2.0, 1.99999999, ref)
+    assert np.max(np.abs(out_c[:, 4] / ref - 1.0)) < 5e-16
+    # rotate_double in numpy float64, statement for statement (the direction is float32, widened where the reference widens it)
+    x, y, z = (d[:, k].copy() for k in range(3))
+    dxy = (x * x + y * y).astype(np.float64)
+    norm = dxy + (z * z).astype(np.float64)
+    re = np.abs(norm - 1.0) > 1e-14
+    s = np.where(re, 1.0 / np.sqrt(norm), 1.0)
+    x, y, z = (np.where(re, (s * v.astype(np.float64)).astype(np.float32), v) for v in (x, y, z))
+    dxy = np.where(re, (x * x + y * y).astype(np.float64), dxy)
+    sp, cp = np.sin(phi), np.cos(phi)
+    tilted = dxy > 1e-28
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sdt = np.sqrt((1.0 - costh * costh) / dxy)
+    X, Y, Z = x.astype(np.float64), y.astype(np.float64), z.astype(np.float64)
+    ru = X * costh + sdt * ((x * z).astype(np.float64) * cp - Y * sp)
+    rv = Y * costh + sdt * ((y * z).astype(np.float64) * cp + X * sp)
+    rw = Z * costh - dxy * sdt * cp
+    s0 = np.sqrt(1.0 - costh * costh)
+    ru = np.where(tilted, ru, np.where(z > 0, s0 * cp, -s0 * cp))
+    rv = np.where(tilted, rv, s0 * sp)
+    rw = np.where(tilted, rw, np.where(z > 0, costh, -costh))
+    want = np.stack([ru, rv, rw], axis=1).astype(np.float32).astype(np.float64)
+    ulp = np.spacing(np.maximum(np.abs(want), 2.0 ** -20).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(out[:, 5:8] - want) <= ulp), float(np.max(np.abs(out[:, 5:8] - want) / ulp))
+    assert np.max(np.abs(np.linalg.norm(out[:, 5:8], axis=1) - 1.0)) < 3e-7
+    assert (~tilted).sum() >= 40
