@@ -48,6 +48,19 @@ def measured_ceilings(ctx):
     return {"valu_wave_instructions_per_ns_per_simd": {"64_active_lanes": v[0], "lanes_0_31": v[1], "32_lanes_spread": v[2]},
             "scattered_64bit_atomic_adds_per_s": ctx.microbench("atomic_rate"), "source": "mcgpu_microbench in this run"}
 
+def kernel_name(workload, ctx=None):
+    """The kernel the engine dispatches for this context, as a profiler shows it: track_pool_kernel<volume kind, segment loop, 0> (the
+    per-wave pools of track_fast.hip; last argument 1 = track_fast64.hip) or track_wg_kernel<volume kind> (MCGPU_FAST_SCHED=1)."""
+    if ctx is None:
+        return "track_pool_kernel<...> (fast)"
+    v = kernel_variant(workload, ctx)
+    vk = 4 if v["tile_records"] else (3 if ctx.geti("sub_brick_table") else v["volume_kind"])
+    what = {0: "u8 volume", 1: "u16 volume", 2: "raw float2 volume", 3: "u8 volume + 4-bit sub-brick codes", 4: "u8 volume + tile records"}[vk]
+    if v["fast_scheduler"]:
+        return f"track_wg_kernel<{vk}> (fast, workgroup-level pool, {what})"
+    return f"track_pool_kernel<{vk}, {'true' if v['segment_loop'] else 'false'}, 0> (fast, {what}{', flight segment as an inner loop' if v['segment_loop'] else ''})"
+
+
 def roofline_block(workload, H, k_ms, ceilings=None, ctx=None):
     """`roofline` object of one workload: algorithmic bytes of the reference layout over the measured kernel time, plus the
     PMC-counter traffic of this kernel build when a stamped summary of it is committed."""
@@ -84,7 +97,7 @@ def roofline_block(workload, H, k_ms, ceilings=None, ctx=None):
             "traffic": traffic, "traffic_uncorrected": traffic_raw, "hbm_counter_frac": hbm_counter_frac, "traffic_source": pmc_src,
             "traffic_note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE as the guide prescribes for gfx950; the factor 2 is calibrated for wide coalesced reads, this kernel gathers 1-16 bytes: the truth lies between traffic_uncorrected and traffic",
             "fabric_bytes_per_history": None if traffic is None else traffic / H, "l2_hit_rate": l2_hit,
-            "kernel": "track_pool_kernel<4> (fast, u8 volume + tile records)" if (ctx is not None and ctx.geti("tile_records")) else "track_pool_kernel<0> (fast, u8 volume)",
+            "kernel": kernel_name(workload, ctx),
             "kernel_ms_avg": k_ms, "kernel_source_sha16": kernel_source_hash(),
             "algorithmic_bytes_per_history": algo_bytes, "algorithmic_bytes_source": algo_src,
             "algorithmic_bytes_per_launch": algo_bytes * H}

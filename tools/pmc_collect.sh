@@ -6,7 +6,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads}
+ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-compat --no-workloads --no-reference-arithmetic}
 i=0
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY" \

@@ -15,6 +15,8 @@ for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=
         if "track_" not in row["Kernel_Name"] or "kernel" not in row["Kernel_Name"]:
             continue
         m = re.search(r"track_\w+<[^>]*>", row["Kernel_Name"])
+        if m and re.search(r",\s*1>$", m.group(0)) and "track_pool_kernel" in m.group(0):
+            continue  # track_fast64.hip's kernel (third template argument 1): not the production kernel this summary is about
         kernels.add(m.group(0) if m else row["Kernel_Name"])
         acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
