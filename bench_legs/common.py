@@ -42,13 +42,22 @@ WORKLOADS = {
 KERNEL_SOURCES = ("track_pool.inc", "track_common.inc", "device_model.hpp", "track_fast.hip")
 
 
+def _code_only(text: str) -> bytes:
+    """A source file without its comments and blank lines (none of the kernel sources holds a string literal with a comment marker):
+    a corrected comment is not another kernel build."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    lines = [re.sub(r"//.*$", "", line).rstrip() for line in text.split("\n")]
+    return "\n".join(line for line in lines if line.strip()).encode()
+
+
 def kernel_source_hash() -> str:
-    """Identifies the FAST kernel build: SHA-256 over its sources and over the compiler flags of track_fast.o (the
-    CXXFLAGS / HIPFLAGS / FASTMATH lines of the Makefile)."""
+    """Identifies the FAST kernel build: SHA-256 over the code of its sources (comments and blank lines removed) and over the compiler
+    flags of track_fast.o (the CXXFLAGS / HIPFLAGS / FASTMATH lines of the Makefile)."""
     h = hashlib.sha256()
     csrc = ROOT / "4d-cbct-mc_amd" / "csrc"
     for name in KERNEL_SOURCES:
-        h.update((csrc / name).read_bytes())
+        h.update(_code_only((csrc / name).read_text()))
     for line in (csrc / "Makefile").read_text().split("\n"):
         if line.startswith(("CXXFLAGS", "HIPFLAGS", "FASTMATH")):
             h.update(line.encode())
