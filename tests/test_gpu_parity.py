@@ -561,12 +561,12 @@ def test_fast64_double_precision_helpers_against_numpy(gpu_engine, case_dir):
     dxy = np.where(re, (x * x + y * y).astype(np.float64), dxy)
     sp, cp = np.sin(phi), np.cos(phi)
     tilted = dxy > 1e-28
-    with np.errstate(divide="ignore", invalid="ignore"):
-        sdt = np.sqrt((1.0 - costh * costh) / dxy)
     X, Y, Z = x.astype(np.float64), y.astype(np.float64), z.astype(np.float64)
-    ru = X * costh + sdt * ((x * z).astype(np.float64) * cp - Y * sp)
-    rv = Y * costh + sdt * ((y * z).astype(np.float64) * cp + X * sp)
-    rw = Z * costh - dxy * sdt * cp
+    with np.errstate(divide="ignore", invalid="ignore"):  # the untilted lanes (dxy = 0) take the other branch below
+        sdt = np.sqrt((1.0 - costh * costh) / dxy)
+        ru = X * costh + sdt * ((x * z).astype(np.float64) * cp - Y * sp)
+        rv = Y * costh + sdt * ((y * z).astype(np.float64) * cp + X * sp)
+        rw = Z * costh - dxy * sdt * cp
     s0 = np.sqrt(1.0 - costh * costh)
     ru = np.where(tilted, ru, np.where(z > 0, s0 * cp, -s0 * cp))
     rv = np.where(tilted, rv, s0 * sp)
