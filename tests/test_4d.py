@@ -62,13 +62,31 @@ def test_set_geometry_arrays_equals_a_fresh_context_on_the_file(engine, tmp_path
 
 
 def test_respiratory_signal_rules():
+    """The rules that decide which projections share a warped geometry (cbctmc/mc/respiratory.py:45-93), stated independently here:
+    resampling = linear interpolation onto int(T f) instants; quantisation = numpy.digitize's right-open classes mapped to their centres
+    (so the maximum sits half a class ABOVE the range); grouping = np.unique(axis=0) order with ascending projection indices."""
     R = cases.pkg.respiratory.RespiratorySignal
-    s = R.create_sin4(total_seconds=20.0, period=5.0, sampling_frequency=25.0).resample(15.0)
+    base = R.create_sin4(total_seconds=20.0, period=5.0, sampling_frequency=25.0)
+    t25 = np.linspace(0, 20.0, 500)
+    assert np.array_equal(base.signal, 1.0 * np.sin(2 * np.pi * (1 / (2 * 5.0)) * t25) ** 4) and np.array_equal(base.time, t25)
+    assert np.array_equal(R.create_cos4(20.0, 5.0, 2.0, 25.0).signal, 2.0 * np.cos(2 * np.pi * (1 / (2 * 5.0)) * t25) ** 4)
+    assert np.array_equal(base.dt_signal, np.gradient(base.signal, 1 / 25.0))
+    s = base.resample(15.0)
+    t15 = np.linspace(0, 20.0, 300)
     assert len(s.signal) == 300 and abs(s.signal.max() - 1.0) < 0.02
-    q = R.quantize_signal(s.signal, n_bins=4)
-    assert len(np.unique(q)) <= 5
-    u = R.get_unique_signals(q, R.quantize_signal(s.dt_signal, n_bins=2))
+    assert np.array_equal(s.signal, np.interp(t15, t25, base.signal)) and np.array_equal(s.dt_signal, np.interp(t15, t25, base.dt_signal))
+    for values, n in ((s.signal, 4), (s.dt_signal, 2), (np.array([0.0, 0.25, 0.5, 0.75, 1.0, 0.1]), 4)):
+        q = R.quantize_signal(values, n_bins=n)
+        edges = np.linspace(values.min(), values.max(), n + 1)
+        want = edges[np.digitize(values, bins=edges) - 1] + 0.5 * (edges[1] - edges[0])
+        assert np.array_equal(q, want) and len(np.unique(q)) <= n + 1
+        assert q[np.argmax(values)] == values.max() + 0.5 * (edges[1] - edges[0])   # the maximum's own class
+    q, dq = R.quantize_signal(s.signal, n_bins=4), R.quantize_signal(s.dt_signal, n_bins=2)
+    u = R.get_unique_signals(q, dq)
     assert sorted(i for v in u.values() for i in v) == list(range(300))
+    samples = np.stack((q, dq), axis=-1)
+    want = {tuple(p.tolist()): np.where((samples == p).all(axis=1))[0].tolist() for p in np.unique(samples, axis=0)}
+    assert list(u.items()) == list(want.items())   # same states, same order, same ascending indices
 
 
 def test_warp_restatement_equals_torch_grid_sample_fixture():
