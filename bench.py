@@ -247,8 +247,12 @@ def main():
                                                "launches": args.steps, "cost_over_value": k64 / k_ms - 1.0, "unit": "histories/s"}
             if not args.no_compat:
                 out["compat"] = compat_leg(ctx, torch, H)
-                out["check"]["fast_vs_compat"] = fast_vs_compat_check(ctx)
+                both = fast_vs_compat_check(ctx, modes=("fast",) if args.no_reference_arithmetic else ("fast", "fast64"))
+                out["check"]["fast_vs_compat"] = both if args.no_reference_arithmetic else both["fast"]
                 failed = failed or not out["check"]["fast_vs_compat"]["passed"]
+                if not args.no_reference_arithmetic:  # the reference-arithmetic variant against the bit-exact personality, same COMPAT launches
+                    out["check"]["fast64_vs_compat"] = both["fast64"]
+                    failed = failed or not both["fast64"]["passed"]
             if not args.no_end_to_end:
                 out["end_to_end"] = end_to_end_scan(ctx, H, workdir, n=min(args.scan_projections, nproj))
                 # the 894-projection scan with stacks, sustained: what the headline's launches become over a whole trajectory
@@ -276,7 +280,8 @@ def main():
                                       "unit": "Gatomic/s", "frac": tally_hits * H / (k_ms * 1e-3) / (a_peak * 1e9),
                                       "detected_photons_per_history": tally_hits}
             out["check"].update(oracle_check(ctx, H, img_cpu, w2_cpu, n_cpu))
-            out["check"]["passed"] = bool(out["check"]["passed"] and out["check"].get("fast_vs_compat", {}).get("passed", True))
+            out["check"]["passed"] = bool(out["check"]["passed"] and out["check"].get("fast_vs_compat", {}).get("passed", True) and
+                                          out["check"].get("fast64_vs_compat", {}).get("passed", True))
             failed = failed or not out["check"]["passed"]
         else:
             out["cpu_baseline"] = None

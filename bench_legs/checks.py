@@ -3,45 +3,50 @@ from __future__ import annotations
 
 import numpy as np
 
-def fast_vs_compat_check(ctx, runs=12, histories=250_000_000, projection=447):
-    """FAST against the bit-exact COMPAT personality (tallies bit-identical to the oracle, tests/test_gpu_parity.py): `runs`
-    independent launches of `histories` per mode, variances from the run-to-run scatter.  Detected energy per history per
-    scatter class: ratio, relative sigma, z.  (tools/fast_vs_compat.py is the long version)"""
+def fast_vs_compat_check(ctx, runs=12, histories=250_000_000, projection=447, modes=("fast",)):
+    """FAST (and, with "fast64" in `modes`, the variant with the reference's double-precision sub-steps) against the bit-exact COMPAT
+    personality (tallies bit-identical to the oracle, tests/test_gpu_parity.py): `runs` independent launches of `histories` per mode,
+    variances from the run-to-run scatter.  Detected energy per history per scatter class: ratio, relative sigma, z.  One mode: the
+    report itself; several: {mode: report} (the COMPAT launches are shared).  (tools/fast_vs_compat.py is the long version)"""
     p = projection % ctx.num_projections
     batches, hpt, _ = ctx.reference_shape(histories)
-    ef, ec = [], []
-    edge = {"fast": [0.0, 0.0, 0.0], "compat": [0.0, 0.0, 0.0]}  # primary energy: all columns, column 1024, beyond column 1024
+    energy = {m: [] for m in tuple(modes) + ("compat",)}
+    edge = {m: [0.0, 0.0, 0.0] for m in energy}  # primary energy: all columns, column 1024, beyond column 1024
     half_fan = ctx.detector_shape[1] == 1848  # the beam ends at the right edge of column 1023 (the reference crops there, projection.py:42-51)
 
-    def note_edge(key, img):
+    def note(key, img, d):
+        energy[key].append(img.reshape(4, -1).sum(axis=1, dtype=np.float64) / d)
         if half_fan:
             edge[key][0] += float(img[0].sum(dtype=np.float64)); edge[key][1] += float(img[0][:, 1024].sum(dtype=np.float64))
             edge[key][2] += float(img[0][:, 1025:].sum(dtype=np.float64))
     for k in range(runs):
-        img, _, d = ctx.run_projection(p, histories, mode="fast", seed=8000 + k)
-        ef.append(img.reshape(4, -1).sum(axis=1, dtype=np.float64) / d)
-        note_edge("fast", img)
+        for j, m in enumerate(modes):
+            img, _, d = ctx.run_projection(p, histories, mode=m, seed=8000 + 500 * j + k)
+            note(m, img, d)
         img, _, d = ctx.run_projection(p, batches, mode="compat", seed=9000 + 7 * k, hpt=hpt)
-        ec.append(img.reshape(4, -1).sum(axis=1, dtype=np.float64) / d)
-        note_edge("compat", img)
-    ef, ec = np.array(ef), np.array(ec)
-    known = None
-    if half_fan and edge["fast"][0] > 0 and edge["compat"][0] > 0:
-        # KNOWN DEVIATION 1 (DESIGN.md 2): the primary beam ends exactly at detector column 1024; photons within a hundredth of a
-        # pixel of that edge fall to either side depending on the last bits of the sampled direction, and FAST (v_sin / v_cos) puts
-        # more of them into column 1024 than the reference arithmetic.  Bounded: excess <= 5e-8 of the primary energy, nothing beyond.
-        ff, cf = edge["fast"][1] / edge["fast"][0], edge["compat"][1] / edge["compat"][0]
-        known = {"what": "primary energy in detector column 1024 (first column beyond the half-fan beam edge), fraction of the primary energy",
-                 "fast": ff, "compat": cf, "excess": ff - cf, "bound_on_excess": 5e-8, "fast_beyond_column_1024": edge["fast"][2],
-                 "compat_beyond_column_1024": edge["compat"][2],
-                 "passed": bool(ff - cf <= 5e-8 and edge["fast"][2] == 0.0)}
-    se = np.sqrt(ef.var(axis=0, ddof=1) / runs + ec.var(axis=0, ddof=1) / runs)
-    z = (ef.mean(axis=0) - ec.mean(axis=0)) / np.where(se > 0, se, 1.0)
-    return {"projection": int(p), "runs_per_mode": runs, "histories_per_run": int(histories), "classes": ["primary", "compton", "rayleigh", "multiple"],
-            "energy_ratio_fast_over_compat": [float(a / b) if b else None for a, b in zip(ef.mean(axis=0), ec.mean(axis=0))],
-            "relative_sigma": [float(a / b) if b else None for a, b in zip(se, ec.mean(axis=0))],
-            "energy_z": [round(float(v), 3) for v in z], "beam_edge_column": known,
-            "passed": bool(np.all(np.abs(z) < 6.0) and (known is None or known["passed"]))}  # Student t with 2 runs - 2 = 22 degrees of freedom: P(|t| > 6) = 5e-6 per class
+        note("compat", img, d)
+    ec = np.array(energy["compat"])
+    out = {}
+    for m in modes:
+        ef = np.array(energy[m])
+        known = None
+        if half_fan and edge[m][0] > 0 and edge["compat"][0] > 0:
+            # KNOWN DEVIATION 1 (DESIGN.md 2): the primary beam ends exactly at detector column 1024; photons within a hundredth of a
+            # pixel of that edge fall to either side depending on the last bits of the sampled direction, and FAST (v_sin / v_cos) puts
+            # more of them into column 1024 than the reference arithmetic.  Bounded: excess <= 5e-8 of the primary energy, nothing beyond.
+            ff, cf = edge[m][1] / edge[m][0], edge["compat"][1] / edge["compat"][0]
+            known = {"what": "primary energy in detector column 1024 (first column beyond the half-fan beam edge), fraction of the primary energy",
+                     "fast": ff, "compat": cf, "excess": ff - cf, "bound_on_excess": 5e-8, "fast_beyond_column_1024": edge[m][2],
+                     "compat_beyond_column_1024": edge["compat"][2],
+                     "passed": bool(ff - cf <= 5e-8 and edge[m][2] == 0.0)}
+        se = np.sqrt(ef.var(axis=0, ddof=1) / runs + ec.var(axis=0, ddof=1) / runs)
+        z = (ef.mean(axis=0) - ec.mean(axis=0)) / np.where(se > 0, se, 1.0)
+        out[m] = {"mode": m, "projection": int(p), "runs_per_mode": runs, "histories_per_run": int(histories), "classes": ["primary", "compton", "rayleigh", "multiple"],
+                  f"energy_ratio_{m}_over_compat" if m != "fast" else "energy_ratio_fast_over_compat": [float(a / b) if b else None for a, b in zip(ef.mean(axis=0), ec.mean(axis=0))],
+                  "relative_sigma": [float(a / b) if b else None for a, b in zip(se, ec.mean(axis=0))],
+                  "energy_z": [round(float(v), 3) for v in z], "beam_edge_column": known,
+                  "passed": bool(np.all(np.abs(z) < 6.0) and (known is None or known["passed"]))}  # Student t with 2 runs - 2 = 22 degrees of freedom: P(|t| > 6) = 5e-6 per class
+    return out[modes[0]] if len(modes) == 1 else out
 
 def entry_face_deficit(ctx, runs=8, fast_histories=10_000_000_000, compat_histories=5_000_000_000, projection=600):
     """The reference's ENTRY-FACE SHELL (rounds 1-4: known deviation 2; reproduced since round 5): it puts an entering photon EPS_SOURCE =
