@@ -325,6 +325,9 @@ def test_bench_line_keeps_the_driver_contract(tmp_path):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "histories/s" and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    # the asterisk on "f32" is resolved in the line itself: the same kernel with the reference's double-precision sub-steps
+    assert "rotate_double" in d["dtype_note"] and 0.5 * d["value"] < d["value_reference_arithmetic"] < 1.02 * d["value"]
+    assert d["reference_arithmetic"]["mode"] == "fast64"
     assert d["value"] > 1e9 and abs(d["value"] - 1e8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
