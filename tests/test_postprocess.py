@@ -205,6 +205,7 @@ def test_device_finalize_and_scan_pipeline(engine, case_dir, tmp_path):
         out.mkdir()
         rep = ctx.run_scan(mode="fast", histories=n_hist, crop_nx=128, write_ascii=True, output_folder=out, air_stack=air_stack, air_sigma=(10, 10))
         assert rep["projections"] == 4 and rep["histories_per_projection"] == n_hist
+        assert 0.0 < rep["kernel_ms_min"] <= rep["kernel_ms_max"] and rep["kernel_ms_min"] * 4 <= rep["seconds_kernels"] * 1e3 * (1 + 1e-6) <= rep["kernel_ms_max"] * 4 * (1 + 2e-6)
         per_proj = [ctx.run_projection(p, n_hist, mode="fast", seed=ctx.geti("seed"))[0] for p in range(4)]
         planes = np.stack([ctx.finalize_host(i, n_hist, crop_nx=128) for i in per_proj])  # [4, 3, nz, 128]
         for k, m in enumerate(("total", "unscattered", "scattered")):
@@ -262,6 +263,8 @@ def test_scan_sharded_over_contexts_equals_single_context(engine, case_dir, tmp_
         try:
             rep = ctxs[0].run_scan(mode="fast", histories=n_hist, crop_nx=128, write_ascii=True, output_folder=out, peers=ctxs[1:])
             assert rep["projections"] == 4 and rep["histories_per_projection"] == n_hist
+            # fastest / slowest projection of the scan (mcgpu_scan_report.kernel_ms_min / _max) bracket the mean kernel time
+            assert 0.0 < rep["kernel_ms_min"] <= rep["seconds_kernels"] * 1e3 / 4 * (1 + 1e-6) and rep["seconds_kernels"] * 1e3 / 4 <= rep["kernel_ms_max"] * (1 + 1e-6)
             ascii_files = [Path(ctxs[0].projection_file_name(p)).read_bytes() for p in range(4)]
         finally:
             for c in ctxs:

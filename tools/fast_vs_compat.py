@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev check (GPU): FAST against the bit-exact COMPAT personality on a bench workload with many histories on both sides.
+"""Dev check (GPU): FAST (MODE=fast64: the variant with the reference's double-precision sub-steps) against the bit-exact COMPAT personality on a bench workload with many histories on both sides.
 K independent runs per mode (different seeds); the run-to-run scatter gives the variances.  Per scatter class: detected energy
 per history, ratio FAST / COMPAT and its z; per 32x32-pixel block: z from the same run-to-run variances.
 Usage: python tools/fast_vs_compat.py <workload> <projection> [runs] [histories per run]"""
@@ -13,7 +13,10 @@ wl, p = sys.argv[1], int(sys.argv[2])
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 n = int(float(sys.argv[4])) if len(sys.argv) > 4 else 500_000_000
 eng = cases.pkg.engine
-inp = Path(f"/tmp/mcgpu_bench_{wl}_512_894/input.in")
+MODE = os.environ.get("MODE", "fast")
+inp = cases.pkg.workloads.workload_dir(wl) / "input.in"
+if not inp.exists():  # a fresh box: the workload's inputs in the reference's wire formats (4d-cbct-mc_amd/workloads.py)
+    cases.pkg.workloads.build_workload(inp.parent, wl, 100_000_000, 894, engine=eng)
 B = 32
 def blocks(img):
     c, nz, nx = img.shape
@@ -23,11 +26,11 @@ with eng.create(inp, device=0) as ctx:
     per = {"fast": [], "compat": []}
     t0 = time.time()
     for k in range(K):
-        img, _, d = ctx.run_projection(p, n, mode="fast", seed=int(os.environ.get("SEED0", "1000")) + k)
+        img, _, d = ctx.run_projection(p, n, mode=MODE, seed=int(os.environ.get("SEED0", "1000")) + k)
         per["fast"].append(blocks(img) / d)
         img, _, d = ctx.run_projection(p, batches, mode="compat", seed=int(os.environ.get("SEED0", "1000")) + 1000 + 7 * k, hpt=hpt)
         per["compat"].append(blocks(img) / d)
-    print(f"{wl} projection {p}: {K} runs of {n:.2e} histories per mode in {time.time() - t0:.1f} s")
+    print(f"{wl} projection {p}, mode {MODE}: {K} runs of {n:.2e} histories per mode in {time.time() - t0:.1f} s")
     F, Cc = np.array(per["fast"]), np.array(per["compat"])          # [K, 4, bz, bx]
     ef, ec = F.sum(axis=(2, 3)), Cc.sum(axis=(2, 3))                 # [K, 4] energy per history per class
     for c, name in enumerate(("primary", "compton", "rayleigh", "multiple")):
