@@ -271,8 +271,10 @@ def test_compat_kernel_reproduces_the_reference_tallies_at_bench_size(workload, 
         assert abs(got[k] - pin["reference"]["class_sums"][k]) <= 1e-6 * max(pin["reference"]["class_sums"][k], 1), (k, got[k], pin["reference"]["class_sums"][k])
 
 
-@pytest.mark.parametrize("workload,p", [("catphan", 447), ("cirs", 300), ("thorax", 600)])
-def test_fast_against_the_bit_exact_personality_with_4e9_histories(workload, p, request):
+@pytest.mark.parametrize("workload,p,mode", [("catphan", 447, "fast"), ("cirs", 300, "fast"), ("thorax", 600, "fast"),
+                                             # the same kernel with the reference's double-precision sub-steps (csrc/track_fast64.hip)
+                                             ("catphan", 447, "fast64"), ("thorax", 600, "fast64")])
+def test_fast_against_the_bit_exact_personality_with_4e9_histories(workload, p, mode, request):
     """The COMPAT kernel (bit-identical to the oracle, 1-3e9 histories/s) as the yardstick of the statistical personality:
     16 independent runs of 2.5e8 histories per mode, variances from the run-to-run scatter.  Detected energy per history per
     scatter class within 5 sigma (sigma ~ 2e-5 for the primary, ~ 4e-4 for the scatter classes), the z of the 32x32-pixel
@@ -289,7 +291,7 @@ def test_fast_against_the_bit_exact_personality_with_4e9_histories(workload, p, 
 
     F, Cc = [], []
     for k in range(K):
-        img, _, d = ctx.run_projection(p, n, mode="fast", seed=4000 + k)
+        img, _, d = ctx.run_projection(p, n, mode=mode, seed=4000 + k)
         F.append(blocks(img) / d)
         img, _, d = ctx.run_projection(p, batches, mode="compat", seed=6000 + 7 * k, hpt=hpt)
         Cc.append(blocks(img) / d)
